@@ -1,0 +1,142 @@
+/*
+ * vdbhip.h -- C-ABI of libvdbhip.so, the MI355X (gfx950) brute-force / IVF-Flat k-NN backend.
+ *
+ * This is the drop-in boundary for ONE hot path of Human-Augment-Analytics/vectordb-retrieval:
+ * what the reference delegates to `faiss.IndexFlat` / `faiss.IndexIVFFlat` / NumPy on behalf of
+ *   src/algorithms/exact_search.py:26-78        ExactSearch.build_index / search / batch_search
+ *   src/algorithms/modular.py:121-133, 312-390  BruteForceIndexer.build, LinearSearcher.*
+ *   src/algorithms/modular.py:244-309, 418-449, 536-548  FaissFactory/IVFIndexer.build, FaissSearcher.*
+ *   src/algorithms/approximate_search.py:28-87  ApproximateSearch (IVFn,Flat keys)
+ *   src/benchmark/dataset.py:497-504, 858-964   brute-force ground truth
+ * Plain pointers and sizes only; no torch / numpy types.  The reference-side binding (ctypes) is
+ * shown in INTEGRATION.md and implemented in vectordb-retrieval_amd/vdbhip/_ffi.py.
+ *
+ * Conventions (identical to faiss.IndexFlat, i.e. what ExactSearch.batch_search returns,
+ * exact_search.py:78):
+ *   metric VDB_METRIC_L2 : distances are SQUARED L2, ascending.
+ *   metric VDB_METRIC_IP : "distances" are raw inner products, descending.
+ *   ids are int64 row numbers (+ id_base of vdb_add); when k > ntotal the tail is padded with
+ *   id -1 and distance +FLT_MAX (L2) / -FLT_MAX (IP).
+ *   Ties are broken by the smaller id (shard-count invariant).
+ * The LinearSearcher / FaissSearcher conventions (sqrt, negated scores, cosine = normalise + IP,
+ * +inf padding; modular.py:355-360, 381-385, 545-546) are applied by the Python shim on the (nq,k) output.
+ *
+ * Exactness contract: the neighbours returned are the exact k nearest under float64 arithmetic
+ *   L2: sum_d fma(t,t,.) with t = (double)x[d]-(double)q[d];  IP: sum_d fma((double)q[d],(double)x[d],.)
+ * (d ascending), the order key being (value, id).  The fp16 MFMA scan only nominates candidates;
+ * every returned neighbour is re-scored in this arithmetic and a rigorous error bound guarantees that
+ * no true neighbour was left out (DESIGN.md "exactness guard").
+ *
+ * Threading: a handle may be used from one host thread at a time.  All calls return a status
+ * code; vdb_last_error() gives the message of the last failure on the calling thread.
+ */
+#ifndef VDBHIP_H
+#define VDBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDB_ABI_VERSION 1
+
+typedef struct vdb_index_s *vdb_handle;
+
+enum vdb_metric { VDB_METRIC_L2 = 0, VDB_METRIC_IP = 1 };
+
+enum vdb_status {
+    VDB_OK = 0,
+    VDB_ERR_INVALID = 1,     /* bad argument (maps to ValueError at build time, RuntimeError at search time) */
+    VDB_ERR_STATE = 2,       /* e.g. search before add: "Index has not been built yet." (exact_search.py:53-54) */
+    VDB_ERR_HIP = 3,         /* HIP runtime failure */
+    VDB_ERR_NOMEM = 4,
+    VDB_ERR_UNSUPPORTED = 5
+};
+
+/* which search path served the last call (vdb_stats_t.last_path) */
+enum vdb_path { VDB_PATH_NONE = 0, VDB_PATH_EXACT_SCAN = 1, VDB_PATH_MFMA_SCAN = 2, VDB_PATH_IVF = 3 };
+
+typedef struct vdb_stats_s {
+    int64_t ntotal;            /* rows indexed */
+    int32_t dim;
+    int32_t metric;
+    int64_t bytes_resident;    /* device bytes owned by the handle (index + workspace) */
+    int32_t last_path;         /* enum vdb_path */
+    int32_t corpus_fp16_exact; /* 1 if every corpus value is exactly representable in the fp16 scan copy */
+    int64_t last_nq;
+    int64_t last_candidates;   /* rows re-scored exactly by the refine kernel in the last search */
+    int64_t last_rescan_bins;  /* 256-row bins re-scanned exactly (collision guard) */
+    int64_t last_fallback_queries; /* queries whose work list overflowed -> exhaustive exact scan */
+    float last_scan_ms;        /* HIP-event time of the dominant (scan) kernel, last search; 0 if not timed */
+    float last_total_ms;       /* HIP-event time of the whole device pipeline, last search; 0 if not timed */
+    int32_t nlist;             /* IVF: number of inverted lists (0 = flat index) */
+    int32_t nprobe;
+} vdb_stats_t;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int vdb_abi_version(void);
+const char *vdb_last_error(void);
+int vdb_device_count(int *count);
+
+/* ---- flat (brute-force) index -- replaces faiss.IndexFlat(d, metric) (exact_search.py:38) -- */
+int vdb_create(int dim, int metric, int device, vdb_handle *out);
+int vdb_destroy(vdb_handle h);
+
+/* replaces index.add(vectors) (exact_search.py:39; modular.py:124-130 keeps the raw matrix):
+ * uploads n rows (row-major float32, host memory) and builds the scan copy.  Row i gets id
+ * id_base + i (row-sharded corpora pass their shard offset).  One-shot: a second call replaces the corpus. */
+int vdb_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
+/* same, rows already in device memory of the handle's GPU */
+int vdb_add_device(vdb_handle h, const float *x_dev, int64_t n, int64_t id_base, void *stream);
+
+/* replaces index.search(queries, k) (exact_search.py:58,78): host buffers, synchronous.
+ * D (nq,k) float32, I (nq,k) int64, caller-allocated. */
+int vdb_search(vdb_handle h, const float *q_host, int64_t nq, int k, float *D, int64_t *I);
+/* device-resident variant: all pointers are device memory on the handle's GPU; work is enqueued on
+ * `stream` (a hipStream_t, NULL = default stream) and NOT synchronised. */
+int vdb_search_device(vdb_handle h, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                      void *stream);
+
+/* ---- row-sharded search (one process per GPU; partials exchanged with an RCCL all-gather) ---- */
+/* per-shard partial top-k: float64 order keys (L2: squared distance, IP: -score) and global ids,
+ * sorted ascending by (key,id); missing entries have id -1 / key +inf. */
+int vdb_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, int k, double *keys_dev,
+                              int64_t *ids_dev, void *stream);
+/* merge nparts partial lists laid out (nparts, nq, k) into the final (nq,k) result. */
+int vdb_merge_partials_device(int metric, int device, const double *keys_dev, const int64_t *ids_dev, int nparts,
+                              int64_t nq, int k, float *D_dev, int64_t *I_dev, void *stream);
+
+/* ---- IVF-Flat -- replaces faiss.index_factory(d, "IVF<nlist>,Flat", metric) + train/add/search
+ *      (modular.py:277-286, 437-441, 544; approximate_search.py:39-51, 87) ------------------- */
+/* k-means (Lloyd) on at most max_points_per_centroid*nlist rows sampled with `seed`; niter iterations. */
+int vdb_ivf_train(vdb_handle h, int nlist, const float *x_host, int64_t n, int niter, uint64_t seed,
+                  int max_points_per_centroid);
+/* inject centroids (nlist, dim) instead of training -- used by parity tests and index loading */
+int vdb_ivf_set_centroids(vdb_handle h, const float *centroids_host, int nlist);
+int vdb_ivf_get_centroids(vdb_handle h, float *centroids_host);
+/* assign rows to their nearest centroid and build the inverted lists (CSR, vectors grouped by list) */
+int vdb_ivf_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
+int vdb_ivf_set_nprobe(vdb_handle h, int nprobe);
+/* list id of each indexed row, int32 (n) -- parity tests compare it with the oracle's assignment */
+int vdb_ivf_get_assignment(vdb_handle h, int32_t *list_of_row_host);
+int vdb_ivf_search(vdb_handle h, const float *q_host, int64_t nq, int k, float *D, int64_t *I);
+int vdb_ivf_search_device(vdb_handle h, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                          void *stream);
+
+/* ---- introspection / tuning ---------------------------------------------------------------- */
+int vdb_stats(vdb_handle h, vdb_stats_t *out);
+/* options: "force_path" (0 auto, 1 exact scan only, 2 MFMA scan when legal), "timing" (0/1: record
+ * HIP-event times into vdb_stats_t), "list_cap" (work-list capacity per query). */
+int vdb_set_option(vdb_handle h, const char *key, double value);
+
+/* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */
+/* raw scan scores (scaled units) for queries x rows [row0,row0+nrows): out (nq, nrows) float32,
+ * together with the per-query bound eps (nq) and the scale cs so that score/cs ~ (||x||^2 - 2 q.x) or -q.x */
+int vdb_debug_scan_scores(vdb_handle h, const float *q_host, int64_t nq, int64_t row0, int64_t nrows,
+                          float *scores_host, float *eps_host, double *cscale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDBHIP_H */

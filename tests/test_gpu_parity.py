@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Bar: neighbour indices bit-exact; distances within 1e-4 relative (north_star) -- in practice they are
+the correctly rounded float32 of the float64 value, so the checks below use 2e-6.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import ref_semantics as rs
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # tolerance stated by BASELINE.json north_star for float distances
+
+
+@pytest.fixture(scope="module")
+def vdb():
+    import vdbhip
+
+    from vdbhip import _ffi
+
+    assert _ffi.device_count() >= 1, "no MI355X visible"
+    return vdbhip
+
+
+def _kat(case):
+    if case == "kat1":
+        r = np.random.RandomState(0)
+        return r.randn(1000, 16).astype(np.float32), r.randn(5, 16).astype(np.float32)
+    if case == "kat2":
+        return rs.random_dataset(128, 10000, 100, 42)
+    if case == "kat3":
+        return rs.random_dataset(64, 20000, 256, 7)
+    raise KeyError(case)
+
+
+def _composite(vdb, dim, metric):
+    return vdb.CompositeAlgorithm(name=f"hip_{metric}", dimension=dim, metric=metric,
+                                  indexer={"type": "HipBruteForceIndexer", "metric": metric},
+                                  searcher={"type": "HipLinearSearcher", "metric": metric})
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors produced by the reference implementation
+# ------------------------------------------------------------------------------------------------
+def test_reference_unit_known_answer(vdb, golden_dir):
+    g = np.load(golden_dir / "kat0_ref_unit.npz")
+    for metric in ("l2", "cosine", "ip"):
+        algo = _composite(vdb, 2, metric)
+        algo.build_index(g["X"])
+        d, i = algo.batch_search(g["Q"], k=2)
+        np.testing.assert_array_equal(i, g[f"I_{metric}"])
+        np.testing.assert_allclose(d, g[f"D_{metric}"], rtol=RTOL, atol=1e-6)
+        assert d.dtype == np.float32 and i.dtype == np.int64
+
+
+@pytest.mark.parametrize("case,fname,k", [("kat1", "kat1_rs0_1000x16.npz", 3),
+                                          ("kat2", "kat2_random_10000x128.npz", 10)])
+@pytest.mark.parametrize("metric", ["l2", "cosine", "ip"])
+def test_golden_linear_searcher_conventions(vdb, golden_dir, case, fname, k, metric):
+    g = np.load(golden_dir / fname)
+    X, Q = _kat(case)
+    algo = _composite(vdb, X.shape[1], metric)
+    algo.build_index(X)
+    d, i = algo.batch_search(Q, k=k)
+    np.testing.assert_array_equal(i, g[f"I_{metric}"])
+    np.testing.assert_allclose(d, g[f"D_{metric}"], rtol=RTOL, atol=1e-6)
+    # single-query API returns 1-D arrays (modular.py:332-334)
+    d1, i1 = algo.search(Q[0], k=k)
+    assert d1.shape == (k,) and i1.shape == (k,)
+    np.testing.assert_array_equal(i1, g[f"I_{metric}"][0])
+
+
+def test_golden_large_k_and_ground_truth(vdb, golden_dir, oracle):
+    g = np.load(golden_dir / "kat3_smoke_20000x64_k100.npz")
+    X, Q = _kat("kat3")
+    algo = vdb.get_algorithm_instance("HipExactSearch", 64, name="exact_hip", metric="l2")
+    algo.build_index(X)
+    d, i = algo.batch_search(Q, k=100)
+    d_o, i_o = oracle.knn(X, Q, 100, "l2")
+    np.testing.assert_array_equal(i, i_o)                 # bit-exact against the canonical oracle
+    np.testing.assert_array_equal(d, d_o)
+    # against the reference's float32 output: identical except inside rounding-size tie bands
+    from tests.helpers import tie_band_mismatch_report
+
+    ka, kb = oracle.pair_keys(X, Q, i, "l2"), oracle.pair_keys(X, Q, g["I_l2"], "l2")
+    assert tie_band_mismatch_report(i, g["I_l2"], ka, kb, band=1e-6) <= 2
+    np.testing.assert_allclose(np.sqrt(d), g["D_l2"], rtol=RTOL)
+    assert rs.recall_at_k(g["GT"], i, 100) == pytest.approx(1.0, abs=1e-4)
+
+
+def test_edge_cases_golden(vdb, golden_dir):
+    g = np.load(golden_dir / "edge_cases.npz")
+    X, Q = g["X"], g["Q"]
+    from tests.helpers import assert_same_neighbours_modulo_ties
+
+    for metric in ("l2", "cosine", "ip"):
+        algo = _composite(vdb, 2, metric)
+        algo.build_index(X)
+        for k in (3, 7):
+            d, i = algo.batch_search(Q, k=k)
+            Dg, Ig = g[f"D_{metric}_k{k}"], g[f"I_{metric}_k{k}"]
+            assert d.dtype == np.float32 and i.dtype == np.int64 and d.shape == (2, k)
+            if k == 7:  # k > N: +inf / -1 padding (modular.py:357-359, 382-384)
+                assert np.all(i[:, 5:] == -1) and np.all(np.isinf(d[:, 5:])) and np.all(d[:, 5:] > 0)
+                assert_same_neighbours_modulo_ties(i[:, :5], Ig[:, :5], d[:, :5], Dg[:, :5])
+            else:
+                np.testing.assert_allclose(d, Dg, rtol=RTOL, atol=1e-6)
+            assert not np.isnan(d).any()
+    # float64 + Fortran-ordered corpus and float64 queries are accepted (modular.py:114-118)
+    r = np.random.RandomState(0)
+    X1 = r.randn(1000, 16).astype(np.float32)
+    Q1 = r.randn(5, 16).astype(np.float32)
+    algo = _composite(vdb, 16, "l2")
+    algo.build_index(np.asfortranarray(X1[:50].astype(np.float64)))
+    d, i = algo.batch_search(Q1.astype(np.float64), k=4)
+    np.testing.assert_array_equal(i, g["I_f64F"])
+    np.testing.assert_allclose(d, g["D_f64F"], rtol=RTOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP path vs canonical oracle on seeded inputs: both kernels paths, both metrics
+# ------------------------------------------------------------------------------------------------
+CASES = [
+    # n, d, nq, k, metric, kind
+    (1, 8, 3, 1, "l2", "gauss"),
+    (7, 3, 5, 4, "ip", "gauss"),
+    (300, 50, 17, 10, "l2", "gauss"),
+    (5000, 128, 64, 10, "ip", "gauss"),
+    (4097, 33, 9, 64, "l2", "gauss"),
+    (3000, 200, 11, 5, "l2", "gauss"),      # D > 128: exhaustive exact kernel
+    (2000, 768, 4, 10, "ip", "gauss"),
+    (40000, 128, 200, 10, "l2", "gauss"),   # MFMA scan path
+    (40000, 128, 200, 10, "ip", "gauss"),
+    (50000, 50, 130, 10, "ip", "glove"),
+    (33000, 64, 64, 1, "l2", "gauss"),
+    (70000, 16, 100, 20, "l2", "gauss"),
+    (100000, 100, 96, 100, "l2", "gauss"),   # k too large for the bin select at this N: exact kernel
+    (120000, 100, 96, 100, "l2", "gauss"),   # k = 100 through the MFMA scan
+    (65536, 128, 256, 10, "l2", "sift"),    # integer-valued: fp16 scan exact, real ties
+]
+
+
+def _make(n, d, nq, kind, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "sift":
+        X = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(n, d))), 0, 218).astype(np.float32)
+        Q = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(nq, d))), 0, 218).astype(np.float32)
+    elif kind == "glove":
+        X = (0.5 * rng.standard_normal((n, d))).astype(np.float32)
+        Q = (0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((nq, d)).astype(np.float32)
+    return X, Q
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric,kind", CASES)
+def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
+    X, Q = _make(n, d, nq, kind, seed=n + d + k)
+    idx = vdb.FlatIndex(d, metric, 0)
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    st = idx.stats()
+    Do, Io = oracle.knn(X, Q, k, metric)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    # the bin select needs the superbins (two per >=512-row chunk) to outnumber k four to one
+    if n >= 32768 and nq >= 64 and d <= 128 and (n + 511) // 512 >= 2 * k:
+        assert st["last_path_name"] == "mfma_scan", st
+        assert st["last_fallback_queries"] == 0, st
+    else:
+        assert st["last_path_name"] == "exact_scan", st
+    # the forced other path must give the same bits
+    if d <= 128 and n >= 8192 and k * 4 <= n // 512:
+        idx.set_option("force_path", 2 if st["last_path_name"] == "exact_scan" else 1)
+        D2, I2 = idx.search(Q, k)
+        np.testing.assert_array_equal(I2, Io)
+        np.testing.assert_array_equal(D2, Do)
+    idx.close()
+
+
+def test_duplicates_and_exact_ties_use_smaller_id(vdb, oracle):
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 6, size=(4000, 32)).astype(np.float32)      # many equal distances
+    X = np.concatenate([base, base[:1500], base[:700]])                 # exact duplicates
+    rng.shuffle(X, axis=0)
+    X = np.tile(X, (7, 1))[:40000]
+    Q = rng.integers(0, 6, size=(128, 32)).astype(np.float32)
+    for metric in ("l2", "ip"):
+        idx = vdb.FlatIndex(32, metric, 0)
+        idx.add(X)
+        D, I = idx.search(Q, 16)
+        Do, Io = oracle.knn(X, Q, 16, metric)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+        assert idx.stats()["last_path_name"] == "mfma_scan"
+        idx.close()
+
+
+def test_work_list_overflow_takes_the_exhaustive_pass(vdb, oracle):
+    X, Q = _make(40000, 64, 96, "gauss", 3)
+    idx = vdb.FlatIndex(64, "l2", 0)
+    idx.add(X)
+    idx.set_option("list_cap", 1)          # every query overflows its candidate list
+    D, I = idx.search(Q, 10)
+    st = idx.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 96, st
+    Do, Io = oracle.knn(X, Q, 10, "l2")
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    idx.close()
+
+
+def test_zero_vectors_and_degenerate_inputs(vdb, oracle):
+    X = np.zeros((33000, 16), np.float32)       # every distance ties: all queries must fall back, ids 0..k-1
+    X[100] = 1.0
+    Q = np.zeros((64, 16), np.float32)
+    Q[1] = 1.0
+    idx = vdb.FlatIndex(16, "l2", 0)
+    idx.add(X)
+    D, I = idx.search(Q, 5)
+    Do, Io = oracle.knn(X, Q, 5, "l2")
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert I[0].tolist() == [0, 1, 2, 3, 4] and I[1, 0] == 100
+    idx.close()
+
+
+def test_fp16_scan_error_bound_holds(vdb):
+    """|score - exact| <= eps for every (query,row): the premise of the exactness guard."""
+    for kind, metric in (("gauss", "l2"), ("gauss", "ip"), ("sift", "l2"), ("glove", "ip")):
+        X, Q = _make(4096, 128 if kind != "glove" else 50, 48, kind, 11)
+        idx = vdb.FlatIndex(X.shape[1], metric, 0)
+        idx.add(X)
+        scores, eps, cs = idx.debug_scan_scores(Q, 0, 4096)
+        X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
+        dots = Q64 @ X64.T
+        exact = ((X64 * X64).sum(1)[None, :] - 2.0 * dots) if metric == "l2" else -dots
+        err = np.abs(scores.astype(np.float64) / cs - exact)
+        bound = (eps.astype(np.float64) / cs)[:, None]
+        assert np.all(err <= bound), (kind, metric, float(err.max()), float(bound.min()))
+        if kind == "sift":
+            assert idx.stats()["corpus_fp16_exact"] == 1
+            assert float(err.max()) == 0.0          # integer data: the fp16 MFMA scan is exact
+        idx.close()
+
+
+def test_search_errors_are_runtime_errors(vdb):
+    algo = vdb.get_algorithm_instance("HipExactSearch", 4, name="e", metric="l2")
+    with pytest.raises(RuntimeError, match="Index has not been built yet."):
+        algo.batch_search(np.zeros((2, 4), np.float32), 3)
+    algo.build_index(np.eye(4, dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        algo.batch_search(np.zeros((2, 5), np.float32), 3)          # wrong dimension: never ValueError
+    with pytest.raises(RuntimeError):
+        algo.batch_search(np.zeros((2, 4), np.float32), 0)
+    c = _composite(vdb, 2, "dot")
+    c.build_index(np.zeros((3, 2), np.float32))
+    with pytest.raises(ValueError, match="Unsupported metric 'dot'"):   # modular.py:387
+        c.batch_search(np.zeros((1, 2), np.float32), 1)
+
+
+def test_exact_search_metric_mapping_and_padding(vdb, oracle):
+    """ExactSearch: 'cosine' means raw inner product, no normalisation (exact_search.py:23)."""
+    X, Q = _make(500, 24, 9, "gauss", 2)
+    X *= np.linspace(0.1, 3.0, 500, dtype=np.float32)[:, None]
+    a = vdb.HipExactSearch("e", 24, metric="cosine")
+    a.build_index(X)
+    d, i = a.batch_search(Q, k=6)
+    do, io = oracle.knn(X, Q, 6, "ip")
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(d, do)
+    assert np.all(np.diff(d, axis=1) <= 0)      # raw inner products, descending
+    d, i = a.batch_search(Q, k=600)             # k > N: faiss padding
+    assert np.all(i[:, 500:] == -1) and np.all(d[:, 500:] == -np.finfo(np.float32).max)
+    d1, i1 = a.search(Q[0], k=6)
+    np.testing.assert_array_equal(i1, io[0])
+    assert a.get_operations()["ndis"] == 9 * 500 + 9 * 500
+    assert a.get_memory_usage() > 0
+
+
+def test_sharded_partials_merge_is_shard_count_invariant(vdb, oracle):
+    torch = pytest.importorskip("torch")
+    X, Q = _make(90000, 64, 128, "gauss", 9)
+    k = 10
+    dev = torch.device("cuda:0")
+    q_t = torch.from_numpy(Q).to(dev)
+    for metric in ("l2", "ip"):
+        Do, Io = oracle.knn(X, Q, k, metric)
+        for bounds in ([0, 90000], [0, 33000, 90000], [0, 100, 40000, 40001, 90000]):
+            parts = len(bounds) - 1
+            keys = torch.empty((parts, 128, k), dtype=torch.float64, device=dev)
+            ids = torch.empty((parts, 128, k), dtype=torch.int64, device=dev)
+            shards = []
+            for p in range(parts):
+                lo, hi = bounds[p], bounds[p + 1]
+                s = vdb.FlatIndex(64, metric, 0)
+                s.add(X[lo:hi], id_base=lo)
+                s.search_partial_device(q_t.data_ptr(), 128, k, keys[p].data_ptr(), ids[p].data_ptr())
+                shards.append(s)
+            D = torch.empty((128, k), dtype=torch.float32, device=dev)
+            I = torch.empty((128, k), dtype=torch.int64, device=dev)
+            vdb.merge_partials_device(metric, 0, keys.data_ptr(), ids.data_ptr(), parts, 128, k, D.data_ptr(),
+                                      I.data_ptr())
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(I.cpu().numpy(), Io)
+            np.testing.assert_array_equal(D.cpu().numpy(), Do)
+            for s in shards:
+                s.close()

@@ -1,0 +1,145 @@
+"""CPU-only tests: the plugin surface mirrors the reference's, and the C-ABI library loads and exports
+every symbol include/vdbhip.h declares (no compute calls without a GPU)."""
+from __future__ import annotations
+
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    from vdbhip import _ffi
+
+    header = (ROOT / "include" / "vdbhip.h").read_text()
+    declared = set(re.findall(r"\b(vdb_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vdb_index_s"}
+    assert declared, "no declarations parsed"
+    lib = _ffi.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libvdbhip.so does not export {name}"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    assert lib.vdb_abi_version() == 1
+    # error plumbing works without a GPU: a null handle is rejected with a message
+    st = _ffi.Stats()
+    assert lib.vdb_stats(None, ctypes.byref(st)) == _ffi.VDB_ERR_INVALID
+    assert "null handle" in _ffi.last_error()
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    from vdbhip import _ffi
+    import vdbhip
+
+    if _ffi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    algo = vdbhip.HipExactSearch("e", 4, metric="l2")
+    with pytest.raises((RuntimeError, ValueError)):
+        algo.build_index(np.zeros((8, 4), np.float32))
+    with pytest.raises(RuntimeError, match="Index has not been built yet."):
+        algo.batch_search(np.zeros((1, 4), np.float32), 1)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing in the product tree may import, load or link it."""
+    pkg = ROOT / "vectordb-retrieval_amd"
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|liboracle|oracle/_build|c_oracle|ref_semantics", re.M)
+    files = [p for ext in ("*.py", "*.hip", "*.hpp", "*.inc", "Makefile") for p in pkg.rglob(ext)]
+    assert files
+    for path in files:
+        assert not pat.search(path.read_text()), f"{path} references the oracle"
+
+
+def test_base_algorithm_operation_counters():
+    """tests/algorithms/test_base_algorithm.py of the reference."""
+    from vdbhip import BaseAlgorithm
+
+    class Dummy(BaseAlgorithm):
+        def build_index(self, vectors, metadata=None):
+            return None
+
+        def search(self, query, k=10):
+            return np.array([]), np.array([])
+
+        def batch_search(self, queries, k=10):
+            return np.array([[]]), np.array([[]])
+
+    a = Dummy(name="dummy", dimension=2, alpha=3)
+    a.record_operation("distance", 1)
+    a.record_operation("distance", 2.5)
+    a.record_operation("insert", 3)
+    np.testing.assert_allclose(a.operation_counter["distance"], 3.5)
+    np.testing.assert_allclose(a.operation_counter["insert"], 3)
+    ops = a.get_operations()
+    ops["distance"] = 10
+    np.testing.assert_allclose(a.operation_counter["distance"], 3.5)
+    assert a.get_name() == "dummy" and a.get_parameters() == {"alpha": 3}
+    assert a.index_built is False and a.build_time == -1.0 and a.index_memory_usage == -1.0
+    with pytest.raises(NotImplementedError):
+        a.save_index("/tmp/x")
+    with pytest.raises(NotImplementedError):
+        a.load_index("/tmp/x")
+    assert "dummy" in str(a)
+
+
+def test_registry_and_composite_error_conventions(golden_dir):
+    import vdbhip
+
+    errs = json.loads((golden_dir / "manifest.json").read_text())["errors"]
+    # empty indexer / searcher dicts (tests/test_composite_algorithm.py:88-105 of the reference)
+    with pytest.raises(ValueError) as e:
+        vdbhip.CompositeAlgorithm(name="x", dimension=4, indexer={}, searcher={"type": "HipLinearSearcher"})
+    assert str(e.value) == errs["empty_indexer"][1]
+    with pytest.raises(ValueError):
+        vdbhip.CompositeAlgorithm(name="x", dimension=4, indexer={"type": "HipBruteForceIndexer"}, searcher={})
+    with pytest.raises(ValueError, match="must include a 'type' field"):
+        vdbhip.CompositeAlgorithm(name="x", dimension=4, indexer={"metric": "l2"},
+                                  searcher={"type": "HipLinearSearcher"})
+    with pytest.raises(ValueError, match="Unknown searcher type 'Nope'"):
+        vdbhip.get_searcher_class("Nope")
+    with pytest.raises(ValueError, match="Unknown indexer type"):
+        vdbhip.get_indexer_class("Nope")
+    with pytest.raises(ValueError, match="Unknown algorithm type"):
+        vdbhip.get_algorithm_instance("Nope", 4)
+    algo = vdbhip.CompositeAlgorithm(name="c", dimension=4, metric="cosine",
+                                     indexer={"type": "HipBruteForceIndexer", "metric": "cosine"},
+                                     searcher={"type": "HipLinearSearcher", "metric": "cosine", "nprobe": 3})
+    with pytest.raises(RuntimeError) as e:
+        algo.batch_search(np.zeros((1, 4), np.float32), 1)
+    assert str(e.value) == errs["search_before_build"][1]
+    cfg = algo.get_parameters()
+    assert cfg["metric"] == "cosine" and cfg["searcher"]["params"] == {"nprobe": 3}
+    json.dumps(cfg)  # must be JSON serialisable (experiment_runner.py:468, 746-749)
+    for key in ("Composite", "CompositeAlgorithm", "Modular", "HipExactSearch"):
+        assert key in vdbhip.ALGORITHM_REGISTRY
+    inst = vdbhip.get_algorithm_instance("HipExactSearch", 8, name="exact_hip", metric="cosine", nprobe=4)
+    assert inst.name == "exact_hip" and inst.metric == "ip" and inst.get_parameters() == {"nprobe": 4}
+
+
+def test_recall_metric_matches_reference_known_answers(golden_dir):
+    from vdbhip.metrics import recall_at_k
+
+    man = json.loads((golden_dir / "manifest.json").read_text())["recall_at_k"]
+    gt, pr = np.array(man["gt"]), np.array(man["pred"])
+    for key, k in (("r1", 1), ("r2", 2), ("r4", 4), ("r10", 10)):
+        assert recall_at_k(gt, pr, k) == pytest.approx(man[key])
+
+
+def test_synthetic_datasets_match_reference_recipe(golden_dir):
+    import hashlib
+
+    from vdbhip import datasets
+
+    man = json.loads((golden_dir / "manifest.json").read_text())["cases"]["kat2_random_10000x128"]
+    X, Q = datasets.random_reference(128, 10000, 100, 42)
+    assert hashlib.sha256(X.tobytes()).hexdigest() == man["sha_X"]
+    assert hashlib.sha256(Q.tobytes()).hexdigest() == man["sha_Q"]
+    xs, qs = datasets.sift_like(2000, 50, 128, 1234)
+    assert xs.dtype == np.float32 and np.all(xs == np.rint(xs)) and xs.min() >= 0 and xs.max() <= 218
+    assert 400 < np.linalg.norm(xs, axis=1).mean() < 560
+    xs2, _ = datasets.sift_like(2000, 50, 128, 1234)
+    np.testing.assert_array_equal(xs, xs2)

@@ -1,0 +1,88 @@
+// common.hpp -- shared declarations of libvdbhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace vdb {
+
+// ---- geometry of the fp16 scan copy ("panels") ---------------------------------------------
+// The corpus copy that feeds v_mfma_f32_32x32x16_f16 is stored in HBM in A-fragment order:
+//   panels[tile][kstep][lane][8 x fp16]   (1 KiB per (tile,kstep): one wave-wide 16-B load)
+// tile = 32 MFMA rows; kstep = 16 dims; lane l holds MFMA row (l & 31), dims 16*kstep + 8*(l>>5) + 0..7.
+// MFMA row rho of tile t in span s maps to corpus row  512*s + 256*h + 16*t + r  with
+//   r = (rho & 3) | ((rho >> 3) << 2),  h = (rho >> 2) & 1
+// which is exactly the (accumulator register r, lane half h) that sees that row in the C/D layout
+//   row = (r & 3) + 8*(r >> 2) + 4*h.  So one lane half walks 256 CONSECUTIVE corpus rows per span:
+// a "bin" (the unit of the collision guard) is a contiguous 256-row range and the 8-bit id packed
+// into a score is the offset inside the bin.
+constexpr int kTileRows = 32;
+constexpr int kSpanRows = 512;      // 16 tiles; two bins (h = 0,1) of 256 rows
+constexpr int kBinRows = 256;
+constexpr int kTilesPerSpan = 16;
+constexpr int kStageTiles = 4;      // tiles per LDS stage (128 MFMA rows)
+constexpr int kMaxKSteps = 8;       // register-resident query fragments: D <= 128
+constexpr float kPadBias = 1.0e38f; // accumulator init of padding rows (scan units): never selected
+
+struct IndexStats {       // filled on device by the corpus-prep kernels
+    unsigned absmax_bits; // bits of max |x|
+    unsigned maxnorm2_bits; // bits of max ||x||^2 (float)
+    int nonfinite;        // any NaN/Inf
+    int not_integer;      // any non-integer value
+    int not_fp16_exact;   // any value changed by the scaled fp16 conversion
+    int pad[3];
+};
+
+struct QueryBatchInfo {   // per search call, device resident
+    unsigned absmax_bits;
+    int not_integer;
+    int not_fp16_exact;
+    int nonfinite;
+    float sq;             // power-of-two query scale
+    float cs;             // sq * sx : scale of the scan scores
+    float bscale;         // factor applied to the B operand (-2*sq for L2, -sq for IP)
+    int force_fallback;   // scales unusable (non-finite input / overflow): every query takes the exhaustive path
+};
+
+// work list entry of the refine kernel: rows [row0, row0+count)
+struct Range {
+    int64_t row0;
+    int32_t count;
+    int32_t pad;
+};
+
+// ---- order keys --------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t sortable_u64(double v) {
+    uint64_t u = *reinterpret_cast<uint64_t *>(&v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ __device__ inline double unsortable_f64(uint64_t k) {
+    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return *reinterpret_cast<double *>(&u);
+}
+__host__ __device__ inline unsigned sortable_u32(float v) {
+    unsigned u = *reinterpret_cast<unsigned *>(&v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unsortable_f32(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return *reinterpret_cast<float *>(&u);
+}
+
+// ---- host-side error plumbing -------------------------------------------------------------------
+struct Error : public std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define VDB_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            throw ::vdb::Error(3, std::string(#expr) + " failed: " + hipGetErrorString(e__));      \
+    } while (0)
+
+}  // namespace vdb

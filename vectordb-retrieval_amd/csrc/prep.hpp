@@ -1,0 +1,214 @@
+// prep.hpp -- build-time and per-batch preparation kernels (HBM-bound, run once per corpus / batch).
+#pragma once
+#include "common.hpp"
+
+namespace vdb {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void atomic_max_bits(unsigned *addr, float v) {
+    atomicMax(addr, __float_as_uint(fabsf(v)));  // |v| >= 0: integer order == float order
+}
+
+// ---- corpus statistics + exact row norms -----------------------------------------------------------
+// one thread per row: ||x||^2 in float64 (rounded once to float32), max |x|, integer / finite flags.
+__global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restrict__ X, int64_t N, int D4,
+                                                           float *__restrict__ xnorm2, IndexStats *st) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float amax = 0.f;
+    float n2 = 0.f;
+    int nonfinite = 0, notint = 0;
+    if (row < N) {
+        const float4 *xv = reinterpret_cast<const float4 *>(X + (size_t)row * D4);
+        double acc = 0.0;
+        for (int i = 0; i < D4 / 4; ++i) {
+            const float4 a = xv[i];
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = fma((double)v[j], (double)v[j], acc);
+                amax = fmaxf(amax, fabsf(v[j]));
+                nonfinite |= !(fabsf(v[j]) <= 3.402823466e+38f);
+                notint |= (v[j] != rintf(v[j]));
+            }
+        }
+        n2 = (float)acc;
+        xnorm2[row] = n2;
+    }
+    // wave reduce, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o));
+        n2 = fmaxf(n2, __shfl_xor(n2, o));
+    }
+    const int anyf = __any(nonfinite), anyi = __any(notint);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_bits(&st->absmax_bits, amax);
+        atomic_max_bits(&st->maxnorm2_bits, n2);
+        if (anyf) atomicOr(&st->nonfinite, 1);
+        if (anyi) atomicOr(&st->not_integer, 1);
+    }
+}
+
+// ---- corpus panels: fp16 copy in MFMA A-fragment order (see common.hpp) ---------------------------
+// one thread per (tile, kstep, lane): converts 8 consecutive dims of one corpus row.
+__global__ __launch_bounds__(256) void build_panels_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
+                                                           int ksteps, int64_t ntiles, float sx,
+                                                           half8 *__restrict__ panels, IndexStats *st) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ksteps);
+    const int64_t tile = tk / ksteps;
+    int inexact = 0;
+    if (tile < ntiles) {
+        const int rho = lane & 31, kh = lane >> 5;
+        const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+        const int64_t span = tile / kTilesPerSpan;
+        const int t = (int)(tile - span * kTilesPerSpan);
+        const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+        const int d0 = ks * 16 + kh * 8;
+        half8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = d0 + j;
+            float v = 0.f;
+            if (row < N && d < D) v = X[(size_t)row * D4 + d] * sx;
+            const _Float16 hv = (_Float16)v;
+            inexact |= ((float)hv != v);
+            out[j] = hv;
+        }
+        panels[gid] = out;
+    }
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+}
+
+// bias (C-init of the MFMA accumulators): ||x||^2 for L2, 0 for IP, pad marker beyond N.
+__global__ __launch_bounds__(256) void build_bias_kernel(const float *__restrict__ xnorm2, int64_t N, int64_t Npad,
+                                                         int metric, float *__restrict__ bias) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Npad) bias[i] = (i < N) ? (metric == 0 ? xnorm2[i] : 0.f) : kPadBias;
+}
+
+// ---- queries ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void query_stats_kernel(const float *__restrict__ Q, int64_t total,
+                                                          QueryBatchInfo *info) {
+    float amax = 0.f;
+    int nonfinite = 0, notint = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = Q[i];
+        amax = fmaxf(amax, fabsf(v));
+        nonfinite |= !(fabsf(v) <= 3.402823466e+38f);
+        notint |= (v != rintf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const int anyf = __any(nonfinite), anyi = __any(notint);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_bits(&info->absmax_bits, amax);
+        if (anyf) atomicOr(&info->nonfinite, 1);
+        if (anyi) atomicOr(&info->not_integer, 1);
+    }
+}
+
+// one thread: choose the power-of-two query scale for this batch
+__global__ void query_finalize_kernel(QueryBatchInfo *info, float sx, int metric, int corpus_int_unscaled,
+                                      float maxnorm2) {
+    const float amax = __uint_as_float(info->absmax_bits);
+    const float f = (metric == 0) ? 2.f : 1.f;
+    float sq = 1.f;
+    const bool int_ok = corpus_int_unscaled && !info->not_integer && f * amax <= 2048.f;
+    if (!int_ok && amax > 0.f && amax <= 3.0e38f) {
+        int e;
+        frexpf(f * amax, &e);           // f*amax = m * 2^e, m in [0.5,1)
+        sq = ldexpf(1.f, 14 - e);       // f*amax*sq in [8192, 16384)
+    }
+    info->sq = sq;
+    info->cs = sq * sx;
+    info->bscale = -f * sq;
+    const float top = sq * sx * maxnorm2;
+    info->force_fallback = (info->nonfinite || !(top < 1.0e30f) || !(sq * sx > 1.0e-30f)) ? 1 : 0;
+}
+
+// fp16 B-fragment panels of the query batch + padded float32 copy for the refine kernel.
+// thread per (qtile32, kstep, lane)
+__global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restrict__ Q, int64_t nq, int D, int D4,
+                                                            int ksteps, int64_t nqtiles,
+                                                            const QueryBatchInfo *__restrict__ info,
+                                                            half8 *__restrict__ qpanels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ksteps);
+    const int64_t qt = tk / ksteps;
+    if (qt >= nqtiles) return;
+    const float bs = info->bscale;
+    const int64_t q = qt * 32 + (lane & 31);
+    const int d0 = ks * 16 + (lane >> 5) * 8;
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = d0 + j;
+        float v = 0.f;
+        if (q < nq && d < D) v = Q[(size_t)q * D + d] * bs;
+        out[j] = (_Float16)v;
+    }
+    qpanels[gid] = out;
+}
+
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, int64_t n, int D, int D4,
+                                                       float *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D4) return;
+    const int64_t r = i / D4;
+    const int d = (int)(i - r * D4);
+    dst[i] = d < D ? src[(size_t)r * D + d] : 0.f;
+}
+
+// per-query error bound of the fp16 scan, in scan (scaled) units -- DESIGN.md "exactness guard".
+struct EpsArgs {
+    const float *Q;
+    int64_t nq;
+    int D;
+    int Dpad;
+    int metric;
+    float xnorm_max;        // max ||x||
+    int corpus_exact;       // fp16 copy of the corpus is exact
+    int corpus_int_unscaled;// corpus integer valued and stored unscaled (sx == 1)
+    float sx;
+    const QueryBatchInfo *info;
+    float *eps;             // [nq]
+};
+
+__global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nq) return;
+    const float bs = a.info->bscale;
+    const double cs = (double)a.info->cs;
+    double n2 = 0.0;
+    int inexact = 0, notint = 0;
+    for (int d = 0; d < a.D; ++d) {
+        const float v = a.Q[(size_t)q * a.D + d];
+        n2 = fma((double)v, (double)v, n2);
+        const float s = v * bs;
+        inexact |= ((float)(_Float16)s != s);
+        notint |= (v != rintf(v));
+    }
+    const double qn = sqrt(n2), Xn = (double)a.xnorm_max;
+    const double u = 1.0 / 2048.0;  // fp16 unit roundoff 2^-11
+    const double ux = a.corpus_exact ? 0.0 : u, uq = inexact ? u : 0.0;
+    const double rel_in = ux + uq + ux * uq;
+    const double mag = (a.metric == 0) ? (Xn * Xn + 2.0 * qn * Xn) : (qn * Xn);
+    double dot_err = rel_in * qn * Xn;
+    if (rel_in > 0.0) dot_err += ldexp(1.0, -36) * sqrt((double)a.D) * qn * Xn;  // fp16 subnormal tail
+    const bool int_exact = a.corpus_int_unscaled && !notint && a.info->sq == 1.f && a.sx == 1.f &&
+                           mag * 1.000001 < 16777216.0;
+    const double acc_err = int_exact ? 0.0 : (double)(a.Dpad + 3) * ldexp(1.0, -23) * mag;
+    const double pack_err = ldexp(1.0, -15) * mag;
+    const double bias_err = (a.metric == 0 && !int_exact) ? ldexp(1.0, -24) * Xn * Xn : 0.0;
+    const double f = (a.metric == 0) ? 2.0 : 1.0;
+    const double eps_true = f * dot_err + acc_err + pack_err + bias_err;
+    double e = cs * eps_true * 1.02;
+    if (!(e < 1.0e37)) e = 1.0e37;
+    a.eps[q] = (float)e + 1.0e-30f;
+}
+
+}  // namespace vdb

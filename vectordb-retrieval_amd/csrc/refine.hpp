@@ -1,0 +1,235 @@
+// refine.hpp -- exact (float64) re-scoring kernels and the partial-list merge.
+//
+// These kernels define the library's canonical arithmetic (see include/vdbhip.h):
+//   L2: acc = fma(t, t, acc), t = (double)x[d] - (double)q[d];   IP: acc = fma((double)q[d], (double)x[d], acc)
+// for d ascending; order key = (sortable(acc or -acc), id).  One lane scores one row (the chain is
+// sequential by definition), one wave owns one (query, split) and keeps its top-k in registers.
+#pragma once
+#include "common.hpp"
+#include "topk.hpp"
+
+namespace vdb {
+
+struct RefineCommon {
+    const float *X;     // [N][D4] float32 rows, zero padded to a multiple of 4 dims
+    const float *Q;     // [nq][D4]
+    int64_t N;
+    int64_t id_base;
+    int D4;
+    int metric;
+    int k;
+};
+
+__device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const float *__restrict__ q, int D4,
+                                              int metric) {
+    const float4 *xv = reinterpret_cast<const float4 *>(x);
+    const float4 *qv = reinterpret_cast<const float4 *>(q);
+    double acc = 0.0;
+    if (metric == 0) {
+#pragma unroll 4
+        for (int i = 0; i < D4 / 4; ++i) {
+            const float4 a = xv[i];
+            const float4 b = qv[i];
+            double t;
+            t = (double)a.x - (double)b.x; acc = fma(t, t, acc);
+            t = (double)a.y - (double)b.y; acc = fma(t, t, acc);
+            t = (double)a.z - (double)b.z; acc = fma(t, t, acc);
+            t = (double)a.w - (double)b.w; acc = fma(t, t, acc);
+        }
+        return sortable_u64(acc);
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < D4 / 4; ++i) {
+            const float4 a = xv[i];
+            const float4 b = qv[i];
+            acc = fma((double)b.x, (double)a.x, acc);
+            acc = fma((double)b.y, (double)a.y, acc);
+            acc = fma((double)b.z, (double)a.z, acc);
+            acc = fma((double)b.w, (double)a.w, acc);
+        }
+        return sortable_u64(-acc);
+    }
+}
+
+template <int KPL>
+__device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon &c, const float *qptr, int64_t row0,
+                                          int64_t row1) {
+    const int lane = threadIdx.x & 63;
+    if (row1 > c.N) row1 = c.N;
+    for (int64_t base = row0; base < row1; base += 64) {
+        const int64_t row = base + lane;
+        const bool valid = row < row1;
+        uint64_t key = ~0ull;
+        if (valid) key = exact_key(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
+        tk.offer(key, c.id_base + row, valid);
+    }
+}
+
+// final (float32 distance, int64 id) rows or partial (float64 key, id) rows
+template <int KPL>
+__device__ __forceinline__ void write_topk(const WaveTopK<KPL> &tk, int metric, float *D, int64_t *I, double *pk,
+                                           int64_t *pi) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+        const int s = e * 64 + lane;
+        if (s < tk.k) {
+            const bool have = s < tk.n;
+            const double kv = have ? unsortable_f64(tk.key[e]) : __builtin_inf();
+            if (D) {
+                float d;
+                if (have)
+                    d = (float)(metric == 0 ? kv : -kv);
+                else
+                    d = (metric == 0) ? 3.402823466e+38f : -3.402823466e+38f;
+                D[s] = d;
+                I[s] = have ? tk.id[e] : -1;
+            } else {
+                pk[s] = kv;
+                pi[s] = have ? tk.id[e] : -1;
+            }
+        }
+    }
+}
+
+// ---- list mode: candidates nominated by the scan + bins to re-scan -------------------------------
+struct RefineListArgs {
+    RefineCommon c;
+    int64_t nq;
+    const int32_t *cand_rows;   // [nq][cand_cap] local row numbers
+    const int32_t *rescan_rows; // [nq][rescan_cap] first row of 256-row bins
+    const int32_t *counts;      // [nq][2] {n_cand, n_rescan}
+    const int32_t *fallback;    // [nq] 1 -> handled by the exhaustive pass
+    int cand_cap;
+    int rescan_cap;
+    float *D;                   // final mode (nullptr -> partial mode)
+    int64_t *I;
+    double *pkeys;              // partial mode: [nq][k]
+    int64_t *pids;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (q >= a.nq) return;
+    if (a.fallback[q]) return;
+    const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+    WaveTopK<KPL> tk;
+    tk.init(a.c.k);
+    int ncand = a.counts[2 * q];
+    int nres = a.counts[2 * q + 1];
+    ncand = ncand < a.cand_cap ? ncand : a.cand_cap;
+    nres = nres < a.rescan_cap ? nres : a.rescan_cap;
+    const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
+    for (int base = 0; base < ncand; base += 64) {
+        const int i = base + lane;
+        bool valid = i < ncand;
+        int64_t row = valid ? (int64_t)cr[i] : 0;
+        valid = valid && row < a.c.N;
+        uint64_t key = ~0ull;
+        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        tk.offer(key, a.c.id_base + row, valid);
+    }
+    const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap;
+    for (int r = 0; r < nres; ++r) {
+        const int64_t row0 = rr[r];
+        scan_rows<KPL>(tk, a.c, qptr, row0, row0 + kBinRows);
+    }
+    const size_t o = (size_t)q * a.c.k;
+    write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
+                    a.pids ? a.pids + o : nullptr);
+}
+
+// ---- exhaustive mode: every row of the shard, split over S waves per query -----------------------
+struct RefineFullArgs {
+    RefineCommon c;
+    const int32_t *qlist;     // optional: slot -> query
+    const int32_t *count_ptr; // optional: number of slots lives on the device
+    int64_t count;            // used when count_ptr == nullptr
+    int S;                    // splits per query
+    int64_t rows_per_split;
+    // S == 1 and final != nullptr: write final rows directly; else partials [slot][S][k]
+    float *D;
+    int64_t *I;
+    double *pkeys;
+    int64_t *pids;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void refine_full_kernel(RefineFullArgs a) {
+    const int64_t waves_total = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
+    const int64_t units = count * a.S;
+    for (int64_t u = wave0; u < units; u += waves_total) {
+        const int64_t slot = u / a.S;
+        const int split = (int)(u - slot * a.S);
+        const int64_t q = a.qlist ? (int64_t)a.qlist[slot] : slot;
+        const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+        WaveTopK<KPL> tk;
+        tk.init(a.c.k);
+        const int64_t r0 = (int64_t)split * a.rows_per_split;
+        scan_rows<KPL>(tk, a.c, qptr, r0, r0 + a.rows_per_split);
+        if (a.D) {
+            const size_t o = (size_t)q * a.c.k;
+            write_topk<KPL>(tk, a.c.metric, a.D + o, a.I + o, nullptr, nullptr);
+        } else {
+            const size_t o = (size_t)u * a.c.k;
+            write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.pkeys + o, a.pids + o);
+        }
+    }
+}
+
+// ---- merge of sorted partial lists ----------------------------------------------------------------
+struct MergeArgs {
+    const double *pkeys;
+    const int64_t *pids;
+    int64_t part_stride; // elements between consecutive parts of one slot
+    int64_t slot_stride; // elements between consecutive slots of one part
+    int nparts;
+    int k;
+    int metric;
+    const int32_t *qlist;     // optional: slot -> output row
+    const int32_t *count_ptr; // optional device-side slot count
+    int64_t count;
+    float *D;                 // final output (nq,k) ...
+    int64_t *I;
+    double *okeys;            // ... or partial output (count,k)
+    int64_t *oids;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves_total = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
+    const int total = a.nparts * a.k;
+    for (int64_t slot = wave0; slot < count; slot += waves_total) {
+        WaveTopK<KPL> tk;
+        tk.init(a.k);
+        for (int base = 0; base < total; base += 64) {
+            const int i = base + lane;
+            bool valid = i < total;
+            uint64_t key = ~0ull;
+            int64_t id = -1;
+            if (valid) {
+                const int p = i / a.k, j = i - p * a.k;
+                const size_t o = (size_t)p * a.part_stride + (size_t)slot * a.slot_stride + j;
+                id = a.pids[o];
+                key = sortable_u64(a.pkeys[o]);
+                valid = id >= 0;
+            }
+            tk.offer(key, id, valid);
+        }
+        const int64_t q = a.qlist ? (int64_t)a.qlist[slot] : slot;
+        const size_t o = (size_t)q * a.k;
+        if (a.D)
+            write_topk<KPL>(tk, a.metric, a.D + o, a.I + o, nullptr, nullptr);
+        else
+            write_topk<KPL>(tk, a.metric, nullptr, nullptr, a.okeys + o, a.oids + o);
+    }
+}
+
+}  // namespace vdb

@@ -1,0 +1,731 @@
+// vdbhip.hip -- host side of libvdbhip.so: handle management, path selection, kernel launches,
+// and the extern "C" entry points declared in include/vdbhip.h.  gfx950 only.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/vdbhip.h"
+#include "common.hpp"
+#include "prep.hpp"
+#include "refine.hpp"
+#include "scan.hpp"
+
+using namespace vdb;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) VDB_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) throw Error(VDB_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Workspace {
+    DevBuf qpad, qpanels, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
+    DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
+    DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
+    DevBuf stage_q, stage_d, stage_i;  // host-API staging
+    size_t bytes() const {
+        const DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+                               &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
+                               &stage_i};
+        size_t s = 0;
+        for (auto b : all) s += b->cap;
+        return s;
+    }
+    void release() {
+        DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+                         &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i};
+        for (auto b : all) b->release();
+    }
+};
+
+}  // namespace
+
+struct vdb_index_s {
+    int device = 0;
+    int dim = 0, D4 = 0, ksteps = 0, metric = 0;
+    int64_t N = 0, Npad = 0, id_base = 0;
+    bool built = false;
+    // index arrays
+    DevBuf x32, xnorm2, panels, bias, stats;
+    // host copies of the corpus statistics
+    float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
+    bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
+    // options
+    int force_path = 0, timing = 0, list_cap = 0;
+    // per-search
+    Workspace ws;
+    vdb_stats_t last{};
+    // timing mode: HIP-event pairs recorded on the search stream around the dominant kernel and the whole
+    // device pipeline of every search since timing was switched on (read back by vdb_stats)
+    std::vector<hipEvent_t> ev_scan, ev_total;   // [2*i], [2*i+1] = start, stop
+    size_t ev_used = 0;
+    // ivf
+    int nlist = 0, nprobe = 1;
+};
+
+namespace {
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+void set_device(int dev) { VDB_HIP(hipSetDevice(dev)); }
+
+constexpr size_t kMaxTimedCalls = 1024;
+
+// returns the slot of this call, or -1 when timing is off / the ring is full
+long timing_begin(vdb_index_s *h, hipStream_t st);
+void timing_mark(vdb_index_s *h, long slot, int which, hipStream_t st);
+
+int kpl_for(int k) {
+    int kpl = 1;
+    while (kpl * 64 < k) kpl *= 2;
+    return kpl;
+}
+
+#define DISPATCH_KPL(kpl, ...)                                    \
+    switch (kpl) {                                                \
+        case 1: { constexpr int KPL = 1; __VA_ARGS__; } break;           \
+        case 2: { constexpr int KPL = 2; __VA_ARGS__; } break;           \
+        case 4: { constexpr int KPL = 4; __VA_ARGS__; } break;           \
+        case 8: { constexpr int KPL = 8; __VA_ARGS__; } break;           \
+        case 16: { constexpr int KPL = 16; __VA_ARGS__; } break;         \
+        case 32: { constexpr int KPL = 32; __VA_ARGS__; } break;         \
+        default: throw Error(VDB_ERR_UNSUPPORTED, "k too large"); \
+    }
+
+void launch_refine_full(const RefineFullArgs &a, int64_t max_units, hipStream_t st) {
+    int64_t blocks = (max_units + 3) / 4;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 8192));
+    const int kpl = kpl_for(a.c.k);
+    DISPATCH_KPL(kpl, (refine_full_kernel<KPL><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a)));
+    VDB_HIP(hipGetLastError());
+}
+
+void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
+    int64_t blocks = (max_slots + 3) / 4;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 4096));
+    const int kpl = kpl_for(a.k);
+    DISPATCH_KPL(kpl, (merge_kernel<KPL><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a)));
+    VDB_HIP(hipGetLastError());
+}
+
+// ---- index build ---------------------------------------------------------------------------------
+void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base,
+                 hipStream_t st) {
+    if (n < 0) throw Error(VDB_ERR_INVALID, "negative row count");
+    if (n > 2147483647ll - 1024) throw Error(VDB_ERR_UNSUPPORTED, "more than 2^31 rows per shard");
+    const int D = h->dim, D4 = h->D4;
+    h->built = false;
+    h->N = n;
+    h->id_base = id_base;
+    h->Npad = (n + kSpanRows - 1) / kSpanRows * kSpanRows;
+    h->scan_ok = false;
+    if (n == 0) {
+        h->built = true;
+        return;
+    }
+    h->x32.reserve((size_t)n * D4 * sizeof(float));
+    if (D4 != D) VDB_HIP(hipMemsetAsync(h->x32.p, 0, (size_t)n * D4 * sizeof(float), st));
+    VDB_HIP(hipMemcpy2DAsync(h->x32.p, (size_t)D4 * 4, x_dev_or_host, (size_t)D * 4, (size_t)D * 4, (size_t)n,
+                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    h->xnorm2.reserve((size_t)n * sizeof(float));
+    h->stats.reserve(sizeof(IndexStats));
+    VDB_HIP(hipMemsetAsync(h->stats.p, 0, sizeof(IndexStats), st));
+    corpus_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D4, h->xnorm2.as<float>(), h->stats.as<IndexStats>());
+    VDB_HIP(hipGetLastError());
+    IndexStats hs;
+    VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipStreamSynchronize(st));
+    memcpy(&h->absmax, &hs.absmax_bits, 4);
+    memcpy(&h->maxnorm2, &hs.maxnorm2_bits, 4);
+    h->nonfinite = hs.nonfinite != 0;
+    h->corpus_int_unscaled = !hs.not_integer && !h->nonfinite && h->absmax <= 2048.f;
+    h->sx = 1.f;
+    if (!h->corpus_int_unscaled && h->absmax > 0.f && !h->nonfinite) {
+        int e;
+        frexpf(h->absmax, &e);
+        h->sx = ldexpf(1.f, 14 - e);  // absmax*sx in [8192, 16384)
+    }
+    const bool dims_ok = D <= 16 * kMaxKSteps;
+    if (dims_ok && !h->nonfinite) {
+        const int64_t ntiles = h->Npad / kTileRows;
+        h->panels.reserve((size_t)ntiles * h->ksteps * 64 * sizeof(half8));
+        const int64_t threads = ntiles * h->ksteps * 64;
+        build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
+        VDB_HIP(hipGetLastError());
+        h->bias.reserve((size_t)h->Npad * sizeof(float));
+        build_bias_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(h->xnorm2.as<float>(), n, h->Npad, h->metric, h->bias.as<float>());
+        VDB_HIP(hipGetLastError());
+        VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        h->corpus_fp16_exact = hs.not_fp16_exact == 0;
+        h->scan_ok = true;
+    }
+    h->built = true;
+}
+
+// ---- geometry of the scan for a given (N, k) --------------------------------------------------------
+struct ScanGeom {
+    bool ok = false;
+    int64_t nspans = 0;
+    int spc = 0, nchunks = 0, vpl = 0;
+};
+
+ScanGeom scan_geometry(const vdb_index_s *h, int k) {
+    ScanGeom g;
+    g.nspans = h->Npad / kSpanRows;
+    if (g.nspans < 8) return g;
+    // superbins (2 per chunk) must comfortably outnumber k and fit 16 values per lane in the select
+    int64_t spc_hi = g.nspans / (2 * (int64_t)k);           // nsb >= 4k
+    int64_t spc_lo = (g.nspans + 511) / 512;                // nsb <= 1024
+    if (spc_hi < 1 || spc_hi < spc_lo) return g;
+    int64_t spc = std::min<int64_t>(16, spc_hi);
+    spc = std::max<int64_t>(spc, spc_lo);
+    if (spc < 2 && g.nspans >= 64) spc = std::min<int64_t>(2, spc_hi);
+    g.spc = (int)spc;
+    g.nchunks = (int)((g.nspans + spc - 1) / spc);
+    const int nsb = 2 * g.nchunks;
+    g.vpl = 1;
+    while (g.vpl * 64 < nsb) g.vpl *= 2;
+    if (g.vpl > 16) return g;
+    g.ok = true;
+    return g;
+}
+
+template <int VPL>
+void launch_select(const SelectArgs &a, hipStream_t st) {
+    select_kernel<VPL><<<dim3((unsigned)((a.nq + 3) / 4)), dim3(256), 0, st>>>(a);
+}
+
+long timing_begin(vdb_index_s *h, hipStream_t st) {
+    if (!h->timing || h->ev_used >= kMaxTimedCalls) return -1;
+    const size_t slot = h->ev_used++;
+    while (h->ev_scan.size() < 2 * (slot + 1)) {
+        hipEvent_t e;
+        VDB_HIP(hipEventCreate(&e));
+        h->ev_scan.push_back(e);
+        VDB_HIP(hipEventCreate(&e));
+        h->ev_total.push_back(e);
+    }
+    VDB_HIP(hipEventRecord(h->ev_total[2 * slot], st));
+    return (long)slot;
+}
+
+// which: 0 = dominant kernel starts, 1 = dominant kernel done, 2 = pipeline done
+void timing_mark(vdb_index_s *h, long slot, int which, hipStream_t st) {
+    if (slot < 0) return;
+    hipEvent_t e = which == 0 ? h->ev_scan[2 * slot] : which == 1 ? h->ev_scan[2 * slot + 1] : h->ev_total[2 * slot + 1];
+    VDB_HIP(hipEventRecord(e, st));
+}
+
+// ---- one query batch ---------------------------------------------------------------------------------
+// outputs: final (D,I) or partial (pk,pi); all device pointers for rows [0,nq) of this batch
+void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, int64_t *I, double *pk, int64_t *pi,
+                  hipStream_t st) {
+    Workspace &ws = h->ws;
+    const int Dm = h->dim, D4 = h->D4;
+    // float32 queries padded to D4 for the refine kernels
+    const float *qpad = dq;
+    if (D4 != Dm) {
+        ws.qpad.reserve((size_t)nq * D4 * sizeof(float));
+        pad_rows_kernel<<<dim3((unsigned)((nq * D4 + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, ws.qpad.as<float>());
+        VDB_HIP(hipGetLastError());
+        qpad = ws.qpad.as<float>();
+    }
+    RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k};
+
+    ScanGeom g;
+    bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
+    if (use_scan) g = scan_geometry(h, k);
+    use_scan = use_scan && g.ok && (h->force_path == 2 || (nq >= 64 && h->N >= 32768));
+
+    ws.small.reserve(64);
+    VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
+    int32_t *fb_count = ws.small.as<int32_t>();
+    unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 16);
+
+    const long tslot = timing_begin(h, st);
+
+    if (!use_scan) {
+        // exhaustive exact scan, split over S waves per query
+        int64_t S = (8192 + nq - 1) / nq;
+        S = std::min<int64_t>(S, std::max<int64_t>(1, h->N / 1024));
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
+        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
+        RefineFullArgs fa{};
+        fa.c = rc;
+        fa.count = nq;
+        fa.S = (int)S;
+        fa.rows_per_split = (h->N + S - 1) / S;
+        if (fa.rows_per_split < 1) fa.rows_per_split = 1;
+        timing_mark(h, tslot, 0, st);
+        if (S == 1 && D) {
+            fa.D = D;
+            fa.I = I;
+            launch_refine_full(fa, nq, st);
+        } else if (S == 1) {
+            fa.pkeys = pk;
+            fa.pids = pi;
+            launch_refine_full(fa, nq, st);
+        } else {
+            ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
+            ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
+            fa.pkeys = ws.pkeys.as<double>();
+            fa.pids = ws.pids.as<int64_t>();
+            launch_refine_full(fa, nq * S, st);
+            MergeArgs ma{};
+            ma.pkeys = fa.pkeys;
+            ma.pids = fa.pids;
+            ma.part_stride = k;
+            ma.slot_stride = S * k;
+            ma.nparts = (int)S;
+            ma.k = k;
+            ma.metric = h->metric;
+            ma.count = nq;
+            ma.D = D;
+            ma.I = I;
+            ma.okeys = pk;
+            ma.oids = pi;
+            launch_merge(ma, nq, st);
+        }
+        h->last.last_path = VDB_PATH_EXACT_SCAN;
+        timing_mark(h, tslot, 1, st);
+        timing_mark(h, tslot, 2, st);
+        return;
+    }
+
+    // ---- MFMA scan path ------------------------------------------------------------------------------
+    const int64_t Qpad = (nq + 511) / 512 * 512;
+    const int nqtiles = (int)(Qpad / 512);
+    const int64_t nbins = g.nspans * 2, nsb = (int64_t)g.nchunks * 2;
+    const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
+    const int rescan_cap = std::max(16, k / 2 + 8);
+    ws.info.reserve(sizeof(QueryBatchInfo));
+    ws.qpanels.reserve((size_t)(Qpad / 32) * h->ksteps * 64 * sizeof(half8));
+    ws.eps.reserve((size_t)nq * sizeof(float));
+    ws.bin_m1.reserve((size_t)nbins * Qpad * sizeof(float));
+    ws.bin_m2.reserve((size_t)nbins * Qpad * sizeof(float));
+    ws.sb_m1.reserve((size_t)nsb * Qpad * sizeof(float));
+    ws.sb_m2.reserve((size_t)nsb * Qpad * sizeof(float));
+    ws.sb_span.reserve((size_t)nsb * Qpad * sizeof(int32_t));
+    ws.cand.reserve((size_t)nq * cand_cap * sizeof(int32_t));
+    ws.rescan.reserve((size_t)nq * rescan_cap * sizeof(int32_t));
+    ws.counts.reserve((size_t)nq * 2 * sizeof(int32_t));
+    ws.fallback.reserve((size_t)nq * sizeof(int32_t));
+    ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
+
+    QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
+    VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
+    {
+        const int64_t total = nq * Dm;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
+        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2);
+        const int64_t threads = (Qpad / 32) * h->ksteps * 64;
+        build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, h->ksteps, Qpad / 32, info, ws.qpanels.as<half8>());
+        EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
+                   h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
+        query_eps_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(ea);
+        VDB_HIP(hipGetLastError());
+    }
+
+    ScanArgs sa{};
+    sa.panels = h->panels.as<half8>();
+    sa.bias = h->bias.as<float>();
+    sa.qpanels = ws.qpanels.as<half8>();
+    sa.info = info;
+    sa.bin_m1 = ws.bin_m1.as<float>();
+    sa.bin_m2 = ws.bin_m2.as<float>();
+    sa.sb_m1 = ws.sb_m1.as<float>();
+    sa.sb_m2 = ws.sb_m2.as<float>();
+    sa.sb_span = ws.sb_span.as<int32_t>();
+    sa.nspans = g.nspans;
+    sa.spans_per_chunk = g.spc;
+    sa.nchunks = g.nchunks;
+    sa.nqtiles = nqtiles;
+    sa.Qpad = Qpad;
+    const unsigned grid = 8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)nqtiles;
+    timing_mark(h, tslot, 0, st);
+    if (h->ksteps == 4)
+        scan_kernel<4><<<dim3(grid), dim3(512), 0, st>>>(sa);
+    else
+        scan_kernel<8><<<dim3(grid), dim3(512), 0, st>>>(sa);
+    VDB_HIP(hipGetLastError());
+    timing_mark(h, tslot, 1, st);
+
+    SelectArgs se{};
+    se.bin_m1 = sa.bin_m1;
+    se.bin_m2 = sa.bin_m2;
+    se.sb_m1 = sa.sb_m1;
+    se.sb_m2 = sa.sb_m2;
+    se.sb_span = sa.sb_span;
+    se.eps = ws.eps.as<float>();
+    se.info = info;
+    se.nq = nq;
+    se.Qpad = Qpad;
+    se.nspans = g.nspans;
+    se.N = h->N;
+    se.spans_per_chunk = g.spc;
+    se.nchunks = g.nchunks;
+    se.k = k;
+    se.cand_cap = cand_cap;
+    se.rescan_cap = rescan_cap;
+    se.cand_rows = ws.cand.as<int32_t>();
+    se.rescan_rows = ws.rescan.as<int32_t>();
+    se.counts = ws.counts.as<int32_t>();
+    se.fallback = ws.fallback.as<int32_t>();
+    se.fb_list = ws.fb_list.as<int32_t>();
+    se.fb_count = fb_count;
+    se.stat_counters = stat_counters;
+    switch (g.vpl) {
+        case 1: launch_select<1>(se, st); break;
+        case 2: launch_select<2>(se, st); break;
+        case 4: launch_select<4>(se, st); break;
+        case 8: launch_select<8>(se, st); break;
+        default: launch_select<16>(se, st); break;
+    }
+    VDB_HIP(hipGetLastError());
+
+    RefineListArgs la{};
+    la.c = rc;
+    la.nq = nq;
+    la.cand_rows = se.cand_rows;
+    la.rescan_rows = se.rescan_rows;
+    la.counts = se.counts;
+    la.fallback = se.fallback;
+    la.cand_cap = cand_cap;
+    la.rescan_cap = rescan_cap;
+    la.D = D;
+    la.I = I;
+    la.pkeys = pk;
+    la.pids = pi;
+    {
+        const int kpl = kpl_for(k);
+        DISPATCH_KPL(kpl, (refine_list_kernel<KPL><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st>>>(la)));
+        VDB_HIP(hipGetLastError());
+    }
+
+    // queries whose work list overflowed (or whose scales were unusable): exhaustive exact pass
+    {
+        int64_t S = std::min<int64_t>(64, std::max<int64_t>(1, h->N / 4096));
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
+        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
+        ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
+        ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
+        RefineFullArgs fa{};
+        fa.c = rc;
+        fa.qlist = se.fb_list;
+        fa.count_ptr = fb_count;
+        fa.S = (int)S;
+        fa.rows_per_split = (h->N + S - 1) / S;
+        fa.pkeys = ws.pkeys.as<double>();
+        fa.pids = ws.pids.as<int64_t>();
+        launch_refine_full(fa, 1024, st);
+        MergeArgs ma{};
+        ma.pkeys = fa.pkeys;
+        ma.pids = fa.pids;
+        ma.part_stride = k;
+        ma.slot_stride = S * k;
+        ma.nparts = (int)S;
+        ma.k = k;
+        ma.metric = h->metric;
+        ma.qlist = se.fb_list;
+        ma.count_ptr = fb_count;
+        ma.D = D;
+        ma.I = I;
+        ma.okeys = pk;
+        ma.oids = pi;
+        launch_merge(ma, 256, st);
+    }
+    timing_mark(h, tslot, 2, st);
+    h->last.last_path = VDB_PATH_MFMA_SCAN;
+}
+
+void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, int64_t *I, double *pk,
+                        int64_t *pi, hipStream_t st) {
+    if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
+    if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+    if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
+    h->last.last_nq = nq;
+    if (nq == 0) return;
+    if (!dq) throw Error(VDB_ERR_INVALID, "null query pointer");
+    if (h->N == 0) {  // empty shard: all padding
+        MergeArgs ma{};
+        ma.nparts = 0;
+        ma.k = k;
+        ma.metric = h->metric;
+        ma.count = nq;
+        ma.D = D;
+        ma.I = I;
+        ma.okeys = pk;
+        ma.oids = pi;
+        launch_merge(ma, nq, st);
+        h->last.last_path = VDB_PATH_EXACT_SCAN;
+        return;
+    }
+    const int64_t kBatch = 16384;
+    for (int64_t b0 = 0; b0 < nq; b0 += kBatch) {
+        const int64_t nb = std::min<int64_t>(kBatch, nq - b0);
+        search_batch(h, dq + (size_t)b0 * h->dim, nb, k, D ? D + (size_t)b0 * k : nullptr,
+                     I ? I + (size_t)b0 * k : nullptr, pk ? pk + (size_t)b0 * k : nullptr,
+                     pi ? pi + (size_t)b0 * k : nullptr, st);
+    }
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        f();
+        return VDB_OK;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return VDB_ERR_INVALID;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return VDB_ERR_INVALID;
+    }
+}
+
+vdb_index_s *check(vdb_handle h) {
+    if (!h) throw Error(VDB_ERR_INVALID, "null handle");
+    return h;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int vdb_abi_version(void) { return VDB_ABI_VERSION; }
+
+const char *vdb_last_error(void) { return g_last_error.c_str(); }
+
+int vdb_device_count(int *count) {
+    return guarded([&] {
+        if (!count) throw Error(VDB_ERR_INVALID, "null pointer");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) n = 0;
+        *count = n;
+    });
+}
+
+int vdb_create(int dim, int metric, int device, vdb_handle *out) {
+    return guarded([&] {
+        if (!out) throw Error(VDB_ERR_INVALID, "null output handle");
+        if (dim < 1 || dim > 65536) throw Error(VDB_ERR_INVALID, "dimension must be in [1, 65536]");
+        if (metric != VDB_METRIC_L2 && metric != VDB_METRIC_IP) throw Error(VDB_ERR_INVALID, "unknown metric");
+        int n = 0;
+        VDB_HIP(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n) throw Error(VDB_ERR_INVALID, "no such GPU: " + std::to_string(device));
+        set_device(device);
+        hipDeviceProp_t prop;
+        VDB_HIP(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+            throw Error(VDB_ERR_UNSUPPORTED, std::string("libvdbhip is built for gfx950 (MI355X); found ") +
+                                                 prop.gcnArchName);
+        auto *h = new vdb_index_s();
+        h->device = device;
+        h->dim = dim;
+        h->D4 = (dim + 3) / 4 * 4;
+        h->ksteps = dim <= 64 ? 4 : 8;
+        h->metric = metric;
+        *out = h;
+    });
+}
+
+int vdb_destroy(vdb_handle h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats};
+        for (auto b : all) b->release();
+        h->ws.release();
+        for (auto e : h->ev_scan) (void)hipEventDestroy(e);
+        for (auto e : h->ev_total) (void)hipEventDestroy(e);
+        delete h;
+    });
+}
+
+int vdb_add(vdb_handle hh, const float *x_host, int64_t n, int64_t id_base) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (n > 0 && !x_host) throw Error(VDB_ERR_INVALID, "null corpus pointer");
+        set_device(h->device);
+        build_index(h, x_host, false, n, id_base, nullptr);
+    });
+}
+
+int vdb_add_device(vdb_handle hh, const float *x_dev, int64_t n, int64_t id_base, void *stream) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (n > 0 && !x_dev) throw Error(VDB_ERR_INVALID, "null corpus pointer");
+        set_device(h->device);
+        build_index(h, x_dev, true, n, id_base, as_stream(stream));
+    });
+}
+
+int vdb_search(vdb_handle hh, const float *q_host, int64_t nq, int k, float *D, int64_t *I) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
+        if (nq > 0 && (!q_host || !D || !I)) throw Error(VDB_ERR_INVALID, "null pointer");
+        if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+        if (nq <= 0) {
+            if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
+            return;
+        }
+        set_device(h->device);
+        Workspace &ws = h->ws;
+        ws.stage_q.reserve((size_t)nq * h->dim * sizeof(float));
+        ws.stage_d.reserve((size_t)nq * k * sizeof(float));
+        ws.stage_i.reserve((size_t)nq * k * sizeof(int64_t));
+        hipStream_t st = nullptr;
+        VDB_HIP(hipMemcpyAsync(ws.stage_q.p, q_host, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
+        search_device_impl(h, ws.stage_q.as<float>(), nq, k, ws.stage_d.as<float>(), ws.stage_i.as<int64_t>(), nullptr,
+                           nullptr, st);
+        VDB_HIP(hipMemcpyAsync(D, ws.stage_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipMemcpyAsync(I, ws.stage_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int vdb_search_device(vdb_handle hh, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                      void *stream) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (nq > 0 && (!D_dev || !I_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
+        set_device(h->device);
+        search_device_impl(h, q_dev, nq, k, D_dev, I_dev, nullptr, nullptr, as_stream(stream));
+    });
+}
+
+int vdb_search_partial_device(vdb_handle hh, const float *q_dev, int64_t nq, int k, double *keys_dev,
+                              int64_t *ids_dev, void *stream) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (nq > 0 && (!keys_dev || !ids_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
+        set_device(h->device);
+        search_device_impl(h, q_dev, nq, k, nullptr, nullptr, keys_dev, ids_dev, as_stream(stream));
+    });
+}
+
+int vdb_merge_partials_device(int metric, int device, const double *keys_dev, const int64_t *ids_dev, int nparts,
+                              int64_t nq, int k, float *D_dev, int64_t *I_dev, void *stream) {
+    return guarded([&] {
+        if (metric != VDB_METRIC_L2 && metric != VDB_METRIC_IP) throw Error(VDB_ERR_INVALID, "unknown metric");
+        if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+        if (nparts < 0 || nq < 0) throw Error(VDB_ERR_INVALID, "negative size");
+        if (nq == 0) return;
+        if (!D_dev || !I_dev || (nparts > 0 && (!keys_dev || !ids_dev))) throw Error(VDB_ERR_INVALID, "null pointer");
+        set_device(device);
+        MergeArgs ma{};
+        ma.pkeys = keys_dev;
+        ma.pids = ids_dev;
+        ma.part_stride = nq * k;
+        ma.slot_stride = k;
+        ma.nparts = nparts;
+        ma.k = k;
+        ma.metric = metric;
+        ma.count = nq;
+        ma.D = D_dev;
+        ma.I = I_dev;
+        launch_merge(ma, nq, as_stream(stream));
+    });
+}
+
+int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (!out) throw Error(VDB_ERR_INVALID, "null pointer");
+        set_device(h->device);
+        vdb_stats_t s = h->last;
+        s.ntotal = h->N;
+        s.dim = h->dim;
+        s.metric = h->metric;
+        s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
+        s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
+                                     h->ws.bytes());
+        s.nlist = h->nlist;
+        s.nprobe = h->nprobe;
+        s.last_candidates = s.last_rescan_bins = s.last_fallback_queries = 0;
+        s.last_scan_ms = s.last_total_ms = 0.f;
+        if (h->ws.small.p && h->last.last_path == VDB_PATH_MFMA_SCAN) {
+            unsigned char buf[64];
+            VDB_HIP(hipDeviceSynchronize());
+            VDB_HIP(hipMemcpy(buf, h->ws.small.p, 64, hipMemcpyDeviceToHost));
+            int32_t fb;
+            unsigned long long c[2];
+            memcpy(&fb, buf, 4);
+            memcpy(c, buf + 16, 16);
+            s.last_fallback_queries = fb;
+            s.last_candidates = (int64_t)c[0];
+            s.last_rescan_bins = (int64_t)c[1];
+        }
+        if (h->ev_used > 0) {  // averages over every search recorded since timing was switched on
+            double scan = 0.0, total = 0.0;
+            for (size_t i = 0; i < h->ev_used; ++i) {
+                float ms = 0.f;
+                VDB_HIP(hipEventSynchronize(h->ev_total[2 * i + 1]));
+                VDB_HIP(hipEventElapsedTime(&ms, h->ev_scan[2 * i], h->ev_scan[2 * i + 1]));
+                scan += ms;
+                VDB_HIP(hipEventElapsedTime(&ms, h->ev_total[2 * i], h->ev_total[2 * i + 1]));
+                total += ms;
+            }
+            s.last_scan_ms = (float)(scan / h->ev_used);
+            s.last_total_ms = (float)(total / h->ev_used);
+        }
+        *out = s;
+    });
+}
+
+int vdb_set_option(vdb_handle hh, const char *key, double value) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (!key) throw Error(VDB_ERR_INVALID, "null option name");
+        const std::string k(key);
+        if (k == "force_path") {
+            if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "force_path must be 0, 1 or 2");
+            h->force_path = (int)value;
+        } else if (k == "timing") {  // (re)starts the recording window
+            h->timing = value != 0;
+            h->ev_used = 0;
+        } else if (k == "list_cap") {
+            if (value < 0 || value > 65536) throw Error(VDB_ERR_INVALID, "list_cap out of range");
+            h->list_cap = (int)value;
+        } else {
+            throw Error(VDB_ERR_INVALID, "unknown option '" + k + "'");
+        }
+    });
+}
+
+}  // extern "C"
+
+#include "debug_ivf.inc"

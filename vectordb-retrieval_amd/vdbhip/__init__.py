@@ -1,0 +1,17 @@
+"""vdbhip -- MI355X-native exact / IVF-Flat k-NN behind the vectordb-retrieval plugin API.
+
+Importing the package does not touch the GPU and does not import torch; the shared library
+(libvdbhip.so, hand-written HIP for gfx950) is dlopen'ed on first use and there is no CPU fallback.
+"""
+from .plugin_api import (ALGORITHM_REGISTRY, INDEXER_REGISTRY, SEARCHER_REGISTRY, BaseAlgorithm, BaseIndexer,
+                         BaseSearcher, CompositeAlgorithm, IndexArtifact, get_algorithm_instance, get_indexer_class,
+                         get_searcher_class, register_algorithm, register_indexer, register_searcher)
+from .algorithms import HipBruteForceIndexer, HipExactSearch, HipLinearSearcher
+from .index import FlatIndex, merge_partials_device
+
+__all__ = [
+    "ALGORITHM_REGISTRY", "INDEXER_REGISTRY", "SEARCHER_REGISTRY", "BaseAlgorithm", "BaseIndexer", "BaseSearcher",
+    "CompositeAlgorithm", "IndexArtifact", "get_algorithm_instance", "get_indexer_class", "get_searcher_class",
+    "register_algorithm", "register_indexer", "register_searcher", "HipExactSearch", "HipBruteForceIndexer",
+    "HipLinearSearcher", "FlatIndex", "merge_partials_device",
+]
