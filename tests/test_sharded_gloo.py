@@ -1,0 +1,97 @@
+"""N > 1 path on CPU: two gloo ranks drive vdbhip.sharded (shard arithmetic, all-gather layout, merge
+contract).  The per-shard engine is a TEST DOUBLE built on the oracle -- the product engine is HIP only."""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_shard_bounds_cover_rows_exactly():
+    from vdbhip.sharded import shard_bounds
+
+    for n in (0, 1, 7, 8, 9, 1000, 1_000_003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert a <= b == c <= d
+            per = -(-n // world)
+            assert all(b - a <= per for a, b in spans)
+
+
+class _OracleEngine:
+    """CPU stand-in for HipShardEngine (same interface) -- test infrastructure only."""
+
+    def __init__(self, dim, metric, device):
+        import torch
+
+        from oracle import c_oracle
+
+        self.torch, self.o, self.metric = torch, c_oracle, metric
+
+    def add(self, x, id_base):
+        self.x, self.id_base = np.ascontiguousarray(x), id_base
+
+    def to_device(self, q):
+        return self.torch.from_numpy(np.ascontiguousarray(q))
+
+    def search_partial(self, q, k):
+        qn = q.numpy()
+        if len(self.x) == 0:
+            keys = np.full((len(qn), k), np.inf)
+            ids = np.full((len(qn), k), -1, np.int64)
+        else:
+            _, ids, keys = self.o.knn(self.x, qn, k, self.metric, id_base=self.id_base, return_keys=True)
+        return self.torch.from_numpy(keys), self.torch.from_numpy(ids)
+
+    def merge(self, keys_all, ids_all):
+        return self.o.merge_partials(keys_all.numpy(), ids_all.numpy(), self.metric)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path[:0] = [str(ROOT), str(ROOT / "vectordb-retrieval_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from vdbhip.sharded import HipShardedExactSearch
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        X = rng.standard_normal((1001, 24)).astype(np.float32)
+        Q = rng.standard_normal((13, 24)).astype(np.float32)
+        for metric in ("l2", "ip"):
+            algo = HipShardedExactSearch("sh", 24, metric=metric, engine_factory=_OracleEngine)
+            algo.build_index(X)
+            d, i = algo.batch_search(Q, k=7)
+            d1, i1 = algo.search(Q[0], k=7)
+            np.savez(Path(out_dir) / f"r{rank}_{metric}.npz", d=d, i=i, d1=d1, i1=i1,
+                     shard=np.array(algo.shard))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_equal_unsharded(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((1001, 24)).astype(np.float32)
+    Q = rng.standard_normal((13, 24)).astype(np.float32)
+    for metric in ("l2", "ip"):
+        d_ref, i_ref = oracle.knn(X, Q, 7, metric)
+        shards = []
+        for r in range(world):
+            g = np.load(tmp_path / f"r{r}_{metric}.npz")
+            np.testing.assert_array_equal(g["i"], i_ref)      # every rank holds the full, identical result
+            np.testing.assert_array_equal(g["d"], d_ref)
+            np.testing.assert_array_equal(g["i1"], i_ref[0])
+            shards.append(tuple(g["shard"]))
+        assert shards == [(0, 501), (501, 1001)]

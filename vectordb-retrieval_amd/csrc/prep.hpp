@@ -92,20 +92,30 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const float *__restrict
 // ---- queries ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restrict__ Q, int64_t total,
                                                           QueryBatchInfo *info) {
+    __shared__ float s_max[4];
+    __shared__ int s_flags[4];
     float amax = 0.f;
-    int nonfinite = 0, notint = 0;
+    int flags = 0;  // bit0 non-finite, bit1 non-integer
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = Q[i];
         amax = fmaxf(amax, fabsf(v));
-        nonfinite |= !(fabsf(v) <= 3.402823466e+38f);
-        notint |= (v != rintf(v));
+        flags |= (!(fabsf(v) <= 3.402823466e+38f)) | ((v != rintf(v)) << 1);
     }
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    const int anyf = __any(nonfinite), anyi = __any(notint);
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o));
+        flags |= __shfl_xor(flags, o);
+    }
     if ((threadIdx.x & 63) == 0) {
+        s_max[threadIdx.x >> 6] = amax;
+        s_flags[threadIdx.x >> 6] = flags;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one set of atomics per workgroup
+        amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        flags = s_flags[0] | s_flags[1] | s_flags[2] | s_flags[3];
         atomic_max_bits(&info->absmax_bits, amax);
-        if (anyf) atomicOr(&info->nonfinite, 1);
-        if (anyi) atomicOr(&info->not_integer, 1);
+        if (flags & 1) atomicOr(&info->nonfinite, 1);
+        if (flags & 2) atomicOr(&info->not_integer, 1);
     }
 }
 

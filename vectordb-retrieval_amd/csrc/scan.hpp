@@ -35,7 +35,7 @@ struct ScanArgs {
     int64_t nspans;        // total spans (Npad / 512)
     int spans_per_chunk;
     int nchunks;
-    int nqtiles;           // query tiles of 512
+    int nqtiles;           // query tiles (64 * NWAVES queries each)
     int64_t Qpad;          // multiple of 512
 };
 
@@ -48,16 +48,74 @@ __device__ __forceinline__ float fast_min(float a, float b, float neg_inf) {
     return __builtin_amdgcn_fmed3f(a, b, neg_inf);
 }
 
+// ---- phases of one 32-row tile, for one wave (sched_barrier(0) keeps hipcc from blending them) ----------
+template <int KSTEPS, int ABL>
+__device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half8 (&b0)[KSTEPS],
+                                           const half8 (&b1)[KSTEPS], const float16v &cin, float16v &acc0,
+                                           float16v &acc1) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ABL != 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks], b0[ks], ks == 0 ? cin : acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks], b1[ks], ks == 0 ? cin : acc1, 0, 0, 0);
+        } else {
+            if (ks == 0) { acc0 = cin; acc1 = cin; }
+            acc0[ks] += (float)fr[ks][0] * (float)b0[ks][0];
+            acc1[ks] += (float)fr[ks][1] * (float)b1[ks][1];
+        }
+    }
+}
+
+template <int ABL>
+__device__ __forceinline__ void select_phase(const float16v &acc0, const float16v &acc1, float (&m1)[2],
+                                             float (&m2)[2], unsigned idmask, float neg_inf, unsigned id0) {
+    if (ABL == 1) {
+        asm volatile("" ::"v"(acc0), "v"(acc1));
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v0 = pack_score(acc0[r], idmask, id0 + r);
+        m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
+        m1[0] = fast_min(m1[0], v0, neg_inf);
+        const float v1 = pack_score(acc1[r], idmask, id0 + r);
+        m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
+        m1[1] = fast_min(m1[1], v1, neg_inf);
+    }
+}
+
 template <int KSTEPS>
-__global__ __launch_bounds__(512, 2) void scan_kernel(ScanArgs a) {
-    constexpr int kStageVec = kStageTiles * KSTEPS * 64;  // 16-byte vectors per stage
-    constexpr int kLoads = kStageVec / 512;               // per thread (KSTEPS is even)
-    static_assert(kStageVec % 512 == 0, "stage must divide over 512 threads");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + kStageTiles * 32 * 4)];
+__device__ __forceinline__ void read_phase(const half8 *__restrict__ A_tile, const float4 *__restrict__ c_tile,
+                                           half8 (&fr)[KSTEPS], float16v &cin, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) fr[ks] = A_tile[ks * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 c = c_tile[g];
+        cin[4 * g + 0] = c.x; cin[4 * g + 1] = c.y; cin[4 * g + 2] = c.z; cin[4 * g + 3] = c.w;
+    }
+}
+
+// KSTEPS: 16-dim MFMA k-steps (D padded to 16*KSTEPS); NWAVES: waves per workgroup (64 queries each);
+// ST: tiles per LDS stage (divides 16); WPS: waves per SIMD the register allocator must leave room for.
+// ABL: timing-only ablations (wrong results!): 1 = no select epilogue, 2 = no MFMA, 3 = no global loads
+//
+// Phase stagger: a tile costs a wave one MFMA phase (2*KSTEPS back-to-back MFMAs, matrix pipe) and one
+// select phase (96 VALU ops).  The two waves that share a SIMD (wave w and w + NWAVES/2) run them in
+// opposite order -- the "early" half does MFMA(t) then select(t), the "late" half select(t-1) then MFMA(t) --
+// so that while one wave owns the matrix pipe its partner is on the VALU, instead of both queueing for the
+// same pipe (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Both orders do the same work per stage,
+// so the per-stage barrier keeps the stagger locked.
+template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0>
+__global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int kStageVec = ST * KSTEPS * 64;           // 16-byte vectors per stage
+    constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
+    constexpr int SPS = kTilesPerSpan / ST;               // stages per span
+    static_assert(kTilesPerSpan % ST == 0 && ST >= 2, "bad stage geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
-    auto lds_b = [&](int buf) {
-        return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (kStageTiles * 32 * 4));
-    };
+    auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
 
     // ---- block -> (chunk, query tile), XCD aware -------------------------------------------------
     const int b = blockIdx.x;
@@ -66,108 +124,140 @@ __global__ __launch_bounds__(512, 2) void scan_kernel(ScanArgs a) {
     const int chunk = x + 8 * ci;
     if (chunk >= a.nchunks) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int64_t q0 = (int64_t)qt * 512 + wave * 64;  // first query of this wave
+    const bool late = (NWAVES >= 2) && (wave >= NWAVES / 2);
+    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;  // first query of this wave
     const float cs = a.info->cs;
 
     // ---- B fragments: resident for the whole chunk ------------------------------------------------
-    half8 bfrag[2][KSTEPS];
+    half8 b0[KSTEPS], b1[KSTEPS];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
-            bfrag[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KSTEPS + ks) * 64 + lane];
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        b0[ks] = a.qpanels[((size_t)(q0 / 32 + 0) * KSTEPS + ks) * 64 + lane];
+        b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KSTEPS + ks) * 64 + lane];
+    }
 
     const int64_t span0 = (int64_t)chunk * a.spans_per_chunk;
     int64_t span1 = span0 + a.spans_per_chunk;
     if (span1 > a.nspans) span1 = a.nspans;
-    const int nstages = (int)(span1 - span0) * 4;
+    const int nstages = (int)(span1 - span0) * SPS;
 
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
     asm volatile("" : "+v"(NEG_INF));  // opaque, or LLVM folds med3(a,b,-inf) back into a canonicalising fmin
     unsigned idmask = 0xFFFFFF00u;
-    asm volatile("" : "+v"(idmask));  // pin the mask in a VGPR (a literal cannot ride in VOP3 next to an SGPR id)
+    asm volatile("" : "+v"(idmask));   // pin the mask in a VGPR (a literal cannot ride in VOP3 next to an SGPR id)
     float m1[2] = {INF, INF}, m2[2] = {INF, INF};   // level 1 (current bin)
     float M1[2] = {INF, INF}, M2[2] = {INF, INF};   // level 2 (whole chunk)
     int Ms[2] = {0, 0};
 
-    // ---- staging: global -> registers -> LDS, double buffered --------------------------------------
-    half8 stage_a[kLoads];
-    float stage_b = 0.f;
-    auto stage_load = [&](int st) {
-        const int64_t span = span0 + (st >> 2);
-        const int sq4 = st & 3;
-        const half8 *src = a.panels + ((size_t)(span * kTilesPerSpan + sq4 * kStageTiles) * KSTEPS) * 64;
+    // ---- staging: panels go global -> LDS by DMA (global_load_lds, 1 KiB per wave instruction: the panel
+    //      layout is already lane-linear), the 32 bias floats per tile through registers (scaled by cs) -------
+    constexpr int kPieces = kStageVec / 64;            // 1-KiB pieces per stage
+    static_assert(kPieces % NWAVES == 0, "pieces must divide over the waves");
+    float stage_b[kBiasLoads];
+    auto stage_issue = [&](int st, int buf) {
+        const int64_t span = span0 + st / SPS;
+        const int sq = st % SPS;
+        const half8 *src = a.panels + ((size_t)(span * kTilesPerSpan + sq * ST) * KSTEPS) * 64;
+        half8 *dst = lds_a(buf);
 #pragma unroll
-        for (int i = 0; i < kLoads; ++i) stage_a[i] = src[tid + i * 512];
-        if (tid < kStageTiles * 32) {
-            const int t = tid >> 5, hh = (tid >> 4) & 1, r = tid & 15;
-            const float bv = a.bias[span * kSpanRows + hh * kBinRows + (sq4 * kStageTiles + t) * 16 + r];
-            stage_b = (bv >= 0.9e38f) ? kPadBias : bv * cs;
+        for (int i = 0; i < kPieces / NWAVES; ++i) {
+            const int p = wave + i * NWAVES;
+            const half8 *g = src + (ABL == 3 ? (p & 15) : p) * 64 + lane;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
+                reinterpret_cast<__attribute__((address_space(3))) void *>(
+                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < kBiasLoads; ++i) {
+            const int e = tid + i * NT;
+            if (e < ST * 32) {
+                const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+                // raw value only: touching it here would make hipcc drain vmcnt(0), i.e. wait for the DMA
+                stage_b[i] = a.bias[span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r];
+            }
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_bias_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < kLoads; ++i) lds_a(buf)[tid + i * 512] = stage_a[i];
-        if (tid < kStageTiles * 32) lds_b(buf)[tid] = stage_b;
+        for (int i = 0; i < kBiasLoads; ++i)
+            if (tid + i * NT < ST * 32)
+                lds_b(buf)[tid + i * NT] = (stage_b[i] >= 0.9e38f) ? kPadBias : stage_b[i] * cs;
+    };
+    auto flush_span = [&](int64_t span) {  // two bins per lane column are complete: level 1 out, fold level 2
+        const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + (lane & 31);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            a.bin_m1[o + cb * 32] = m1[cb];
+            a.bin_m2[o + cb * 32] = m2[cb];
+            M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+            M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+            m1[cb] = INF;
+            m2[cb] = INF;
+        }
     };
 
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
+    stage_issue(0, 0);
+    stage_bias_store(0);
+    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
 
-    for (int st = 0; st < nstages; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nstages) stage_load(st + 1);
+    half8 fr[KSTEPS];
+    float16v cin, acc0, acc1;
 
-        const half8 *A = lds_a(buf);
-        const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf));
+    if (!late) {
+        // ================= early half: MFMA(t), then select(t) =======================================
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);  // buf^1 was last read before the previous barrier
+            const half8 *A = lds_a(buf);
+            const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
+            const unsigned idS = (unsigned)(((st % SPS) * ST) << 4);
+            read_phase<KSTEPS>(A, B4, fr, cin, lane);
 #pragma unroll
-        for (int t = 0; t < kStageTiles; ++t) {
-            float16v acc0, acc1;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 c = B4[(t * 2 + h) * 4 + g];
-                acc0[4 * g + 0] = c.x; acc0[4 * g + 1] = c.y; acc0[4 * g + 2] = c.z; acc0[4 * g + 3] = c.w;
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, idS + t * 16);
             }
-            acc1 = acc0;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const half8 af = A[(t * KSTEPS + ks) * 64 + lane];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[0][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[1][ks], acc1, 0, 0, 0);
-            }
-            const unsigned idbase = (unsigned)(((st & 3) * kStageTiles + t) * 16);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v0 = pack_score(acc0[r], idmask, idbase + r);
-                m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
-                m1[0] = fast_min(m1[0], v0, NEG_INF);
-                const float v1 = pack_score(acc1[r], idmask, idbase + r);
-                m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
-                m1[1] = fast_min(m1[1], v1, NEG_INF);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((st % SPS) == SPS - 1) flush_span(span0 + st / SPS);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
         }
-
-        if ((st & 3) == 3) {  // a span (two bins per lane column) is complete: flush level 1, fold level 2
-            const int64_t span = span0 + (st >> 2);
-            const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + (lane & 31);
+    } else {
+        // ================= late half: select(t-1), then MFMA(t) =====================================
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                a.bin_m1[o + cb * 32] = m1[cb];
-                a.bin_m2[o + cb * 32] = m2[cb];
-                M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
-                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
-                M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
-                m1[cb] = INF;
-                m2[cb] = INF;
+        for (int r = 0; r < 16; ++r) acc0[r] = 3.0e38f;  // dummy "previous tile": can never win
+        acc1 = acc0;
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const half8 *A = lds_a(buf);
+            const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
+            const unsigned idS = (unsigned)(((st % SPS) * ST) << 4);
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, t == 0 ? ((idS + 240u) & 255u) : idS + (t - 1) * 16);
+                if (t == 0 && st > 0 && (st % SPS) == 0) flush_span(span0 + st / SPS - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
         }
-
-        if (st + 1 < nstages) stage_store(buf ^ 1);
-        __syncthreads();
+        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, 240u);  // drain the very last tile
+        flush_span(span1 - 1);
     }
 
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
@@ -295,6 +385,104 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
     const bool fb = force_fb || ncand > a.cand_cap || nres > a.rescan_cap;
     if (lane == 0) {
+        a.counts[2 * q] = fb ? 0 : ncand;
+        a.counts[2 * q + 1] = fb ? 0 : nres;
+        a.fallback[q] = fb ? 1 : 0;
+        if (fb) {
+            const int pos = atomicAdd(a.fb_count, 1);
+            a.fb_list[pos] = (int)q;
+        } else {
+            atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
+            atomicAdd(&a.stat_counters[1], (unsigned long long)nres);
+        }
+    }
+}
+
+// ---- select, coalesced form: 16 queries per wave, 4 lanes per query ----------------------------------
+// The superbin arrays are [superbin][query]: for one superbin row the 16 queries of a wave are one 64-byte
+// segment, so every lane-instruction reads whole sectors (the one-wave-per-query form above strides by
+// Qpad*4 bytes and is latency bound).  Lane (qi = lane>>2, part = lane&3) keeps superbins part, part+4, ...
+// of query qi in registers; counts are reduced over the 4 lanes with two shuffles.  Work lists are appended
+// through per-query LDS counters.
+template <int V>
+__global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
+    __shared__ int s_cnt[4][16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = lane >> 2, part = lane & 3;
+    const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * 16 + qi;   // < Qpad by construction of the grid
+    const bool qvalid = q < a.nq;
+    const int nsb = a.nchunks * 2;
+    if (part < 2) s_cnt[wave][qi][part] = 0;
+    unsigned v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int s = e * 4 + part;
+        v[e] = (s < nsb) ? sortable_u32(a.sb_m1[(size_t)s * a.Qpad + q]) : 0xFFFFFFFFu;
+    }
+    unsigned ans = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = ans | ((1u << bit) - 1u);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) cnt += (v[e] <= trial) ? 1 : 0;
+        cnt += __shfl_xor(cnt, 1);
+        cnt += __shfl_xor(cnt, 2);
+        if (cnt < a.k) ans |= (1u << bit);
+    }
+    const float tau = unsortable_f32(ans);
+    const float that = tau + 2.0f * (qvalid ? a.eps[q] : 0.f);
+    const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
+    __syncthreads();  // counters zeroed
+    int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1];
+    if (qvalid && !force_fb) {
+        int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
+        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap;
+        // second minimum and span of every ACTIVE superbin, loaded up front so the latencies overlap
+        float sm2v[V];
+        int spanv[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int s = e * 4 + part;
+            const bool act = (s < nsb) && (unsortable_f32(v[e]) <= that);
+            sm2v[e] = act ? a.sb_m2[(size_t)s * a.Qpad + q] : __builtin_inff();
+            spanv[e] = act ? a.sb_span[(size_t)s * a.Qpad + q] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int s = e * 4 + part;
+            if (s >= nsb) continue;
+            const float m1 = unsortable_f32(v[e]);
+            if (!(m1 <= that)) continue;
+            const int hh = s & 1;
+            if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
+                const int pos = atomicAdd(cnt_c, 1);
+                if (pos < a.cand_cap)
+                    cr[pos] = spanv[e] * kSpanRows + hh * kBinRows + (int)(__float_as_uint(m1) & 0xFFu);
+            } else {               // two or more interesting scores: walk the level-1 bins of this superbin
+                const int chunk = s >> 1;
+                const int64_t sp0 = (int64_t)chunk * a.spans_per_chunk;
+                int64_t sp1 = sp0 + a.spans_per_chunk;
+                if (sp1 > a.nspans) sp1 = a.nspans;
+                for (int64_t sp = sp0; sp < sp1; ++sp) {
+                    const size_t o = (size_t)(sp * 2 + hh) * a.Qpad + q;
+                    const float bm1 = a.bin_m1[o];
+                    if (!(bm1 <= that)) continue;
+                    if (a.bin_m2[o] <= that) {
+                        const int pos = atomicAdd(cnt_r, 1);
+                        if (pos < a.rescan_cap) rr[pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                    } else {
+                        const int pos = atomicAdd(cnt_c, 1);
+                        if (pos < a.cand_cap)
+                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + (int)(__float_as_uint(bm1) & 0xFFu));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (qvalid && part == 0) {
+        const int ncand = *cnt_c, nres = *cnt_r;
+        const bool fb = force_fb || ncand > a.cand_cap || nres > a.rescan_cap;
         a.counts[2 * q] = fb ? 0 : ncand;
         a.counts[2 * q + 1] = fb ? 0 : nres;
         a.fallback[q] = fb ? 1 : 0;

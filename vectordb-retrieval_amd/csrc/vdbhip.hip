@@ -75,7 +75,7 @@ struct vdb_index_s {
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
     // options
-    int force_path = 0, timing = 0, list_cap = 0;
+    int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0;
     // per-search
     Workspace ws;
     vdb_stats_t last{};
@@ -215,6 +215,38 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     return g;
 }
 
+// scan kernel variants: {waves per workgroup, tiles per LDS stage, waves per SIMD}.  Variant 0 is the
+// production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
+// ablations of variant 0 and return wrong results).
+struct ScanVariant { int nwaves, st, wps; };
+constexpr ScanVariant kScanVariants[] = {{8, 2, 2}, {8, 4, 2}, {4, 4, 2}, {4, 2, 2}, {8, 2, 2}, {8, 2, 2}, {8, 2, 2},
+                                         {8, 2, 2}, {8, 2, 2}, {8, 2, 2}};
+constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
+
+template <int KSTEPS>
+void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
+    const ScanVariant v = kScanVariants[variant];
+    sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
+    const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
+    switch (variant) {
+        case 1: scan_kernel<KSTEPS, 8, 4, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 2: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
+        case 3: scan_kernel<KSTEPS, 4, 2, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
+        case 7: scan_kernel<KSTEPS, 8, 2, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 8: scan_kernel<KSTEPS, 8, 2, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 9: scan_kernel<KSTEPS, 8, 2, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        default: scan_kernel<KSTEPS, 8, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+    }
+}
+
+void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
+    if (h->ksteps == 4)
+        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st);
+    else
+        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st);
+    VDB_HIP(hipGetLastError());
+}
+
 template <int VPL>
 void launch_select(const SelectArgs &a, hipStream_t st) {
     select_kernel<VPL><<<dim3((unsigned)((a.nq + 3) / 4)), dim3(256), 0, st>>>(a);
@@ -319,7 +351,6 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 
     // ---- MFMA scan path ------------------------------------------------------------------------------
     const int64_t Qpad = (nq + 511) / 512 * 512;
-    const int nqtiles = (int)(Qpad / 512);
     const int64_t nbins = g.nspans * 2, nsb = (int64_t)g.nchunks * 2;
     const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
     const int rescan_cap = std::max(16, k / 2 + 8);
@@ -341,7 +372,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
     {
         const int64_t total = nq * Dm;
-        const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 512);
         query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2);
         const int64_t threads = (Qpad / 32) * h->ksteps * 64;
@@ -365,15 +396,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     sa.nspans = g.nspans;
     sa.spans_per_chunk = g.spc;
     sa.nchunks = g.nchunks;
-    sa.nqtiles = nqtiles;
     sa.Qpad = Qpad;
-    const unsigned grid = 8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)nqtiles;
     timing_mark(h, tslot, 0, st);
-    if (h->ksteps == 4)
-        scan_kernel<4><<<dim3(grid), dim3(512), 0, st>>>(sa);
-    else
-        scan_kernel<8><<<dim3(grid), dim3(512), 0, st>>>(sa);
-    VDB_HIP(hipGetLastError());
+    launch_scan(h, sa, g.nchunks, Qpad, st);
     timing_mark(h, tslot, 1, st);
 
     SelectArgs se{};
@@ -400,12 +425,23 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_list = ws.fb_list.as<int32_t>();
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
-    switch (g.vpl) {
-        case 1: launch_select<1>(se, st); break;
-        case 2: launch_select<2>(se, st); break;
-        case 4: launch_select<4>(se, st); break;
-        case 8: launch_select<8>(se, st); break;
-        default: launch_select<16>(se, st); break;
+    const int nsb_i = 2 * g.nchunks;
+    if (nsb_i <= 256 && h->select_variant == 0) {  // coalesced form: 16 queries per wave
+        const unsigned sgrid = (unsigned)((nq + 63) / 64);
+        if (nsb_i <= 64)
+            select_kernel_v2<16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+        else if (nsb_i <= 128)
+            select_kernel_v2<32><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+        else
+            select_kernel_v2<64><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+    } else {
+        switch (g.vpl) {
+            case 1: launch_select<1>(se, st); break;
+            case 2: launch_select<2>(se, st); break;
+            case 4: launch_select<4>(se, st); break;
+            case 8: launch_select<8>(se, st); break;
+            default: launch_select<16>(se, st); break;
+        }
     }
     VDB_HIP(hipGetLastError());
 
@@ -717,6 +753,11 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "timing") {  // (re)starts the recording window
             h->timing = value != 0;
             h->ev_used = 0;
+        } else if (k == "scan_variant") {
+            if (value < 0 || value >= kNumScanVariants) throw Error(VDB_ERR_INVALID, "scan_variant out of range");
+            h->scan_variant = (int)value;
+        } else if (k == "select_variant") {
+            h->select_variant = value != 0;
         } else if (k == "list_cap") {
             if (value < 0 || value > 65536) throw Error(VDB_ERR_INVALID, "list_cap out of range");
             h->list_cap = (int)value;

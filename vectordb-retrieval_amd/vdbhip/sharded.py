@@ -1,0 +1,142 @@
+"""Row-sharded exact search over the GPUs of one node: one process per GPU, RCCL all-gather of partials.
+
+The reference has no distributed code; this is the MI355X-native scaling path of its brute-force
+hot path.  Rank r of W keeps rows [r*ceil(N/W), min(N, (r+1)*ceil(N/W))) in its own HBM, every
+rank scans its shard for the SAME query batch, the per-shard partial top-k (float64 order keys + global ids,
+`vdb_search_partial_device`) are exchanged with one all-gather each, and every rank merges them with
+`vdb_merge_partials_device`.  The merge key (float64 key, id) makes the result independent of W.
+
+The collective and the shard arithmetic live here; the per-shard engine is pluggable so the N > 1 plumbing is
+testable on CPU with the gloo backend (tests/test_sharded_gloo.py injects a CPU engine built on the oracle --
+the product default is the HIP engine below and there is no CPU fallback).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .plugin_api import BaseAlgorithm, Metadata, SearchResult, register_algorithm
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block of `rank`: [rank*ceil(n/world), min(n, (rank+1)*ceil(n/world)))."""
+    per = -(-n // world) if world > 0 else n
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class HipShardEngine:
+    """Per-rank engine: FlatIndex on this rank's GPU, torch tensors as device buffers."""
+
+    def __init__(self, dim: int, metric: str, device: int):
+        import torch
+
+        from .index import FlatIndex
+
+        self.torch = torch
+        self.metric, self.device = metric, device
+        torch.cuda.set_device(device)
+        self.dev = torch.device("cuda", device)
+        self.index = FlatIndex(dim, metric, device)
+
+    def add(self, x: np.ndarray, id_base: int) -> None:
+        self.index.add(x, id_base=id_base)
+
+    def to_device(self, q: np.ndarray):
+        return self.torch.from_numpy(q).to(self.dev)
+
+    def search_partial(self, q_dev, k: int):
+        t = self.torch
+        nq = q_dev.shape[0]
+        keys = t.empty((nq, k), dtype=t.float64, device=self.dev)
+        ids = t.empty((nq, k), dtype=t.int64, device=self.dev)
+        self.index.search_partial_device(q_dev.data_ptr(), nq, k, keys.data_ptr(), ids.data_ptr(),
+                                         t.cuda.current_stream().cuda_stream)
+        return keys, ids
+
+    def merge(self, keys_all, ids_all) -> Tuple[np.ndarray, np.ndarray]:
+        from .index import merge_partials_device
+
+        t = self.torch
+        parts, nq, k = keys_all.shape
+        D = t.empty((nq, k), dtype=t.float32, device=self.dev)
+        I = t.empty((nq, k), dtype=t.int64, device=self.dev)
+        merge_partials_device(self.metric, self.device, keys_all.data_ptr(), ids_all.data_ptr(), parts, nq, k,
+                              D.data_ptr(), I.data_ptr(), t.cuda.current_stream().cuda_stream)
+        return D.cpu().numpy(), I.cpu().numpy()
+
+
+def all_gather_partials(keys, ids, world: int):
+    """(nq,k) per rank -> (world, nq, k) on every rank.  RCCL over xGMI when the tensors are on GPUs."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return keys.unsqueeze(0), ids.unsqueeze(0)
+    keys_all = torch.empty((world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
+    ids_all = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    if keys.is_cuda:
+        dist.all_gather_into_tensor(keys_all, keys.contiguous())
+        dist.all_gather_into_tensor(ids_all, ids.contiguous())
+    else:  # gloo
+        dist.all_gather(list(keys_all.unbind(0)), keys.contiguous())
+        dist.all_gather(list(ids_all.unbind(0)), ids.contiguous())
+    return keys_all, ids_all
+
+
+class HipShardedExactSearch(BaseAlgorithm):
+    """ExactSearch semantics (exact_search.py:6-78) over a corpus row-sharded across the ranks of the
+    current torch.distributed job.  Every rank passes the FULL corpus / query arrays (as the reference's
+    single-process harness would) and gets the full result back."""
+
+    def __init__(self, name: str, dimension: int, metric: str = "l2", device: Optional[int] = None,
+                 engine_factory: Optional[Callable[[int, str, int], Any]] = None, **kwargs: Any) -> None:
+        super().__init__(name, dimension, **kwargs)
+        self.metric = "l2" if metric == "l2" else "ip"      # exact_search.py:23
+        self._device = device
+        self._engine_factory = engine_factory
+        self.engine = None
+        self.rank, self.world = 0, 1
+        self.ntotal = 0
+
+    def _dist(self):
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def build_index(self, vectors: np.ndarray, metadata: Metadata = None) -> None:
+        import os
+
+        self.rank, self.world = self._dist()
+        x = _ffi.as_f32_c(vectors)
+        if x.ndim != 2 or x.shape[1] != self.dimension:
+            raise ValueError(f"expected (n, {self.dimension}) vectors, got {x.shape}")
+        self.ntotal = int(x.shape[0])
+        lo, hi = shard_bounds(self.ntotal, self.world, self.rank)
+        device = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", self.rank))
+        factory = self._engine_factory or HipShardEngine
+        self.engine = factory(self.dimension, self.metric, device)
+        self.engine.add(x[lo:hi], lo)
+        self.shard = (lo, hi)
+        self.index_built = True
+
+    def batch_search(self, queries: np.ndarray, k: int = 10) -> SearchResult:
+        if not self.index_built:
+            raise RuntimeError("Index has not been built yet.")
+        q = _ffi.as_f32_c(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        keys, ids = self.engine.search_partial(self.engine.to_device(q), int(k))
+        keys_all, ids_all = all_gather_partials(keys, ids, self.world)
+        return self.engine.merge(keys_all, ids_all)
+
+    def search(self, query: np.ndarray, k: int = 10) -> SearchResult:
+        d, i = self.batch_search(np.asarray(query, dtype=np.float32).reshape(1, -1), k)
+        return d[0], i[0]
+
+
+register_algorithm("HipShardedExactSearch", HipShardedExactSearch)
