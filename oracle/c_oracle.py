@@ -53,6 +53,15 @@ def lib() -> ctypes.CDLL:
         L.oracle_merge_partials.argtypes = [f64, i64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                             f32, i64]
         L.oracle_num_threads.restype = ctypes.c_int
+        i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        L.oracle_ivf_assign.restype = ctypes.c_int
+        L.oracle_ivf_assign.argtypes = [f32, ctypes.c_int, ctypes.c_int, f32, ctypes.c_int64, ctypes.c_int, i32,
+                                        ctypes.c_int]
+        L.oracle_ivf_search.restype = ctypes.c_int
+        L.oracle_ivf_search.argtypes = [f32, ctypes.c_int64, ctypes.c_int, f32, ctypes.c_int, i32, f32, ctypes.c_int64,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, f32, i64, ctypes.c_int]
+        L.oracle_kmeans_objective.restype = ctypes.c_double
+        L.oracle_kmeans_objective.argtypes = [f32, ctypes.c_int, ctypes.c_int, f32, ctypes.c_int64, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -109,3 +118,33 @@ def merge_partials(keys: np.ndarray, ids: np.ndarray, metric: str = "l2") -> Tup
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+# ---- IVF-Flat (oracle/ivf_oracle.c) ------------------------------------------------------------------
+def ivf_assign(C: np.ndarray, X: np.ndarray, metric: str = "l2", threads: int = 0) -> np.ndarray:
+    """List (nearest centroid under the index metric, canonical arithmetic) of every row."""
+    C, X = _prep(C), _prep(X)
+    out = np.empty((X.shape[0],), np.int32)
+    rc = lib().oracle_ivf_assign(C, C.shape[0], C.shape[1], X, X.shape[0], _METRIC[metric], out, threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_ivf_assign failed with code {rc}")
+    return out
+
+
+def ivf_search(X, C, list_of_row, Q, k: int, nprobe: int, metric: str = "l2", id_base: int = 0, threads: int = 0):
+    """IVF-Flat search = brute force restricted to the nprobe nearest lists (flat conventions)."""
+    X, C, Q = _prep(X), _prep(C), _prep(Q)
+    lor = np.ascontiguousarray(list_of_row, np.int32)
+    dist = np.empty((Q.shape[0], k), np.float32)
+    ids = np.empty((Q.shape[0], k), np.int64)
+    rc = lib().oracle_ivf_search(X, X.shape[0], X.shape[1], C, C.shape[0], lor, Q, Q.shape[0], k, nprobe,
+                                 _METRIC[metric], id_base, dist, ids, threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_ivf_search failed with code {rc}")
+    return dist, ids
+
+
+def kmeans_objective(C, X, threads: int = 0) -> float:
+    """Mean squared distance of every row to its nearest centroid."""
+    C, X = _prep(C), _prep(X)
+    return float(lib().oracle_kmeans_objective(C, C.shape[0], C.shape[1], X, X.shape[0], threads))

@@ -18,6 +18,7 @@ struct RefineCommon {
     int D4;
     int metric;
     int k;
+    const int64_t *idmap;  // optional: id of row r is idmap[r] (IVF: rows are grouped by list), else id_base + r
 };
 
 __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const float *__restrict__ q, int D4,
@@ -61,7 +62,7 @@ __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon 
         const bool valid = row < row1;
         uint64_t key = ~0ull;
         if (valid) key = exact_key(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
-        tk.offer(key, c.id_base + row, valid);
+        tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
     }
 }
 

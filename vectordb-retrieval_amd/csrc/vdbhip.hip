@@ -12,6 +12,7 @@
 #include "prep.hpp"
 #include "refine.hpp"
 #include "scan.hpp"
+#include "ivf.hpp"
 
 using namespace vdb;
 
@@ -83,8 +84,14 @@ struct vdb_index_s {
     // device pipeline of every search since timing was switched on (read back by vdb_stats)
     std::vector<hipEvent_t> ev_scan, ev_total;   // [2*i], [2*i+1] = start, stop
     size_t ev_used = 0;
-    // ivf
+    // ivf (flat handles leave these empty)
     int nlist = 0, nprobe = 1;
+    bool ivf_built = false;
+    vdb_index_s *coarse = nullptr;           // flat index over the centroids (same metric)
+    std::vector<float> ivf_centroids;        // host copy [nlist][dim]
+    std::vector<int64_t> ivf_offsets_host;   // [nlist+1]
+    std::vector<int32_t> ivf_list_of_row;    // [N] list of every indexed row (original order)
+    DevBuf ivf_offsets, ivf_ids, ivf_probe_d, ivf_probe_i;
 };
 
 namespace {
@@ -287,7 +294,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         VDB_HIP(hipGetLastError());
         qpad = ws.qpad.as<float>();
     }
-    RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k};
+    RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k, nullptr};
 
     ScanGeom g;
     bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
@@ -601,8 +608,10 @@ int vdb_destroy(vdb_handle h) {
         if (!h) return;
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
-        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats};
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->ivf_offsets, &h->ivf_ids,
+                         &h->ivf_probe_d, &h->ivf_probe_i};
         for (auto b : all) b->release();
+        if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
         for (auto e : h->ev_scan) (void)hipEventDestroy(e);
         for (auto e : h->ev_total) (void)hipEventDestroy(e);

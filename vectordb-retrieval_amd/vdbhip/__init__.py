@@ -8,10 +8,13 @@ from .plugin_api import (ALGORITHM_REGISTRY, INDEXER_REGISTRY, SEARCHER_REGISTRY
                          get_searcher_class, register_algorithm, register_indexer, register_searcher)
 from .algorithms import HipBruteForceIndexer, HipExactSearch, HipLinearSearcher
 from .index import FlatIndex, merge_partials_device
+from .ivf import HipApproximateSearch, HipIVFIndexer, HipIVFSearcher, IVFFlatIndex
+from .sharded import HipShardedExactSearch, shard_bounds
 
 __all__ = [
     "ALGORITHM_REGISTRY", "INDEXER_REGISTRY", "SEARCHER_REGISTRY", "BaseAlgorithm", "BaseIndexer", "BaseSearcher",
     "CompositeAlgorithm", "IndexArtifact", "get_algorithm_instance", "get_indexer_class", "get_searcher_class",
     "register_algorithm", "register_indexer", "register_searcher", "HipExactSearch", "HipBruteForceIndexer",
-    "HipLinearSearcher", "FlatIndex", "merge_partials_device",
+    "HipLinearSearcher", "FlatIndex", "merge_partials_device", "HipApproximateSearch", "HipIVFIndexer", "HipIVFSearcher",
+    "IVFFlatIndex", "HipShardedExactSearch", "shard_bounds",
 ]

@@ -1,0 +1,247 @@
+"""IVF-Flat on the MI355X behind the reference's three IVF entry points.
+
+  HipApproximateSearch   drop-in for ApproximateSearch        (src/algorithms/approximate_search.py:6-87)
+                         -- `index_type` keys of the form "IVF<nlist>,Flat" only (PQ/SQ codecs are out of scope,
+                         SURVEY 2 row 6); 'l2' -> squared L2, anything else -> raw inner product; no sign flips.
+  HipIVFIndexer          drop-in for FaissFactoryIndexer / FaissIVFIndexer (modular.py:224-309)
+                         -- cosine = normalise + inner product (:253-262), runtime `nprobe` (:269-275)
+  HipIVFSearcher         drop-in for FaissSearcher on IVF artifacts (modular.py:393-449, 536-548)
+                         -- searcher `nprobe` overrides the indexer's (:437-441), queries normalised when the
+                         artifact says so (:447-448), distances negated for cosine/ip (:545-546).
+
+k-means is this library's own Lloyd iteration (FAISS's is not reproducible without FAISS), defaults mirroring
+FAISS: 25 iterations, seed 1234, at most 256 training points per centroid.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from typing import Any, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .algorithms import _resolve_device, _safe_normalize
+from .plugin_api import (BaseAlgorithm, BaseIndexer, BaseSearcher, IndexArtifact, Metadata, SearchResult,
+                         register_algorithm, register_indexer, register_searcher)
+
+_IVF_KEY = re.compile(r"^\s*IVF(\d+)\s*,\s*Flat\s*$")
+
+
+def parse_ivf_key(key: str) -> int:
+    m = _IVF_KEY.match(str(key))
+    if not m:
+        raise ValueError(f"unsupported index key {key!r}: only 'IVF<nlist>,Flat' is implemented on the HIP backend")
+    return int(m.group(1))
+
+
+class IVFFlatIndex:
+    """Device-resident IVF-Flat index (replaces faiss.index_factory(d, "IVFn,Flat", metric))."""
+
+    def __init__(self, dim: int, nlist: int, metric: str = "l2", device: int = 0):
+        if metric not in ("l2", "ip"):
+            raise ValueError(f"metric must be 'l2' or 'ip', got {metric!r}")
+        self.dim, self.nlist, self.metric, self.device = int(dim), int(nlist), metric, int(device)
+        self._lib = _ffi.load()
+        h = ctypes.c_void_p()
+        _ffi.check(self._lib.vdb_create(self.dim, 0 if metric == "l2" else 1, self.device, ctypes.byref(h)),
+                   build_time=True)
+        self._h = h
+        self.is_trained = False
+        self.ntotal = 0
+        self.nprobe = 1
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vdb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def train(self, x: np.ndarray, niter: int = 25, seed: int = 1234, max_points_per_centroid: int = 256) -> None:
+        x = _ffi.as_f32_c(x)
+        _ffi.check(self._lib.vdb_ivf_train(self._h, self.nlist, _ffi.ptr(x), x.shape[0], int(niter), int(seed),
+                                           int(max_points_per_centroid)), build_time=True)
+        self.is_trained = True
+
+    def set_centroids(self, centroids: np.ndarray) -> None:
+        c = _ffi.as_f32_c(centroids)
+        if c.shape != (self.nlist, self.dim):
+            raise ValueError(f"expected ({self.nlist}, {self.dim}) centroids, got {c.shape}")
+        _ffi.check(self._lib.vdb_ivf_set_centroids(self._h, _ffi.ptr(c), self.nlist), build_time=True)
+        self.is_trained = True
+
+    def centroids(self) -> np.ndarray:
+        out = np.empty((self.nlist, self.dim), np.float32)
+        _ffi.check(self._lib.vdb_ivf_get_centroids(self._h, _ffi.ptr(out)))
+        return out
+
+    def add(self, x: np.ndarray, id_base: int = 0) -> None:
+        x = _ffi.as_f32_c(x)
+        if x.ndim != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected (n, {self.dim}) vectors, got {x.shape}")
+        _ffi.check(self._lib.vdb_ivf_add(self._h, _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
+        self.ntotal = int(x.shape[0])
+
+    def assignment(self) -> np.ndarray:
+        out = np.empty((self.ntotal,), np.int32)
+        _ffi.check(self._lib.vdb_ivf_get_assignment(self._h, _ffi.ptr(out)))
+        return out
+
+    def set_nprobe(self, nprobe: int) -> None:
+        _ffi.check(self._lib.vdb_ivf_set_nprobe(self._h, int(nprobe)), build_time=True)
+        self.nprobe = int(nprobe)
+
+    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _ffi.as_f32_c(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise RuntimeError(f"expected (nq, {self.dim}) queries, got {q.shape}")
+        D = np.empty((q.shape[0], k), np.float32)
+        I = np.empty((q.shape[0], k), np.int64)
+        _ffi.check(self._lib.vdb_ivf_search(self._h, _ffi.ptr(q), q.shape[0], int(k), _ffi.ptr(D), _ffi.ptr(I)))
+        return D, I
+
+    def search_device(self, q_ptr: int, nq: int, k: int, d_ptr: int, i_ptr: int, stream: int = 0) -> None:
+        _ffi.check(self._lib.vdb_ivf_search_device(self._h, q_ptr, int(nq), int(k), d_ptr, i_ptr, stream or None))
+
+    def stats(self) -> dict:
+        s = _ffi.Stats()
+        _ffi.check(self._lib.vdb_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def set_option(self, key: str, value: float) -> None:
+        _ffi.check(self._lib.vdb_set_option(self._h, key.encode(), float(value)), build_time=True)
+
+
+def _build_ivf(vectors: np.ndarray, dim: int, key: str, metric: str, device: int, params: dict) -> IVFFlatIndex:
+    index = IVFFlatIndex(dim, parse_ivf_key(key), metric, device)
+    index.train(vectors, niter=int(params.get("niter", 25)), seed=int(params.get("seed", 1234)),
+                max_points_per_centroid=int(params.get("max_points_per_centroid", 256)))
+    index.add(vectors)
+    return index
+
+
+class HipApproximateSearch(BaseAlgorithm):
+    """ApproximateSearch semantics for "IVF<nlist>,Flat": train -> add -> nprobe from kwargs; raw FAISS
+    conventions (no normalisation, no sign flip)."""
+
+    def __init__(self, name: str, dimension: int, index_type: str, metric: str = "l2", device: Optional[int] = None,
+                 **kwargs: Any) -> None:
+        super().__init__(name, dimension, **kwargs)
+        self.index_type = index_type
+        self.metric = "l2" if metric == "l2" else "ip"      # approximate_search.py:25
+        self.device = _resolve_device(device, kwargs.get("device_ids"))
+        self.index: Optional[IVFFlatIndex] = None
+        parse_ivf_key(index_type)                            # fail at construction, like a bad factory string
+
+    def build_index(self, vectors: np.ndarray, metadata: Metadata = None) -> None:
+        self.vectors = np.asarray(vectors).astype(np.float32)
+        self.index = _build_ivf(self.vectors, self.dimension, self.index_type, self.metric, self.device, self.config)
+        self.index_built = True
+        if "nprobe" in self.config:
+            self.index.set_nprobe(int(self.config["nprobe"]))
+
+    def search(self, query: np.ndarray, k: int = 10) -> SearchResult:
+        if not self.index_built:
+            raise RuntimeError("Index has not been built yet.")
+        d, i = self.index.search(np.array([query], dtype=np.float32), k)
+        return d[0], i[0]
+
+    def batch_search(self, queries: np.ndarray, k: int = 10) -> SearchResult:
+        if not self.index_built:
+            raise RuntimeError("Index has not been built yet.")
+        return self.index.search(np.asarray(queries).astype(np.float32), k)
+
+    def get_memory_usage(self) -> float:
+        return self.index.stats()["bytes_resident"] / (1024.0 * 1024.0) if self.index else 0.0
+
+
+class HipIVFIndexer(BaseIndexer):
+    """FaissFactoryIndexer / FaissIVFIndexer semantics for IVF-Flat keys."""
+
+    _RESERVED = {"index_key", "index_type", "device", "device_ids", "niter", "seed", "max_points_per_centroid"}
+
+    def __init__(self, name: str, dimension: int, metric: str = "l2", index_type: Optional[str] = None,
+                 index_key: Optional[str] = None, **kwargs: Any) -> None:
+        key = index_key or index_type or "IVF100,Flat"
+        params = dict(kwargs)
+        params.setdefault("index_type", key)
+        super().__init__(name, dimension, metric, **params)
+        self.index_key = self.index_type = key
+        parse_ivf_key(key)
+
+    def build(self, vectors: np.ndarray, metadata: Metadata = None) -> IndexArtifact:
+        data = _ffi.as_f32_c(vectors)
+        meta = {"metric": self.metric, "index_key": self.index_key, "faiss_metric": "l2"}
+        metric = "l2"
+        if self.metric == "cosine":
+            data = _safe_normalize(data)
+            metric = "ip"
+            meta.update({"faiss_metric": "ip", "normalize_queries": True, "normalize_vectors": True})
+        elif self.metric == "ip":
+            metric = "ip"
+            meta["faiss_metric"] = "ip"
+        device = _resolve_device(self.params.get("device"), self.params.get("device_ids"))
+        index = _build_ivf(data, self.dimension, self.index_key, metric, device, self.params)
+        if "nprobe" in self.params:                       # runtime attribute of the index (modular.py:269-275)
+            index.set_nprobe(int(self.params["nprobe"]))
+            meta["nprobe"] = self.params["nprobe"]
+        return IndexArtifact(kind="hip_ivf", data=index, metadata=meta)
+
+
+class HipIVFSearcher(BaseSearcher):
+    """FaissSearcher semantics over a HipIVFIndexer artifact."""
+
+    def __init__(self, name: str, dimension: int, metric: str = "l2", **kwargs: Any) -> None:
+        super().__init__(name, dimension, metric, **kwargs)
+        self.index: Optional[IVFFlatIndex] = None
+        self.normalize_queries = False
+
+    def attach(self, artifact: IndexArtifact, vectors: np.ndarray, metadata: Metadata = None) -> None:
+        if artifact.kind != "hip_ivf":
+            raise ValueError("HipIVFSearcher requires 'hip_ivf' artifact")
+        self.index = artifact.data
+        meta = artifact.metadata or {}
+        self.metric = meta.get("metric", self.metric)
+        self.normalize_queries = meta.get("normalize_queries", False)
+        self._prepared = True
+        nprobe = self.params.get("nprobe")
+        if nprobe is None:
+            nprobe = meta.get("nprobe")
+        if nprobe is not None:
+            self.index.set_nprobe(int(nprobe))
+
+    def _prepare_query(self, query: np.ndarray) -> np.ndarray:
+        query = np.asarray(query)
+        if query.ndim == 1:
+            query = query.reshape(1, -1)
+        query = query.astype(np.float32, copy=True)
+        return _safe_normalize(query) if self.normalize_queries else query
+
+    def search(self, query: np.ndarray, k: int = 10) -> SearchResult:
+        d, i = self.batch_search(self._prepare_query(query), k)
+        return d[0], i[0]
+
+    def batch_search(self, queries: np.ndarray, k: int = 10) -> SearchResult:
+        if not self._prepared:
+            raise RuntimeError("FaissSearcher not attached to an index")
+        d, i = self.index.search(self._prepare_query(queries), k)
+        if self.metric in {"cosine", "ip"}:
+            d = -d
+        return d.astype(np.float32), i.astype(np.int64)
+
+    def get_memory_usage(self) -> float:
+        return self.index.stats()["bytes_resident"] / (1024.0 * 1024.0) if self.index else 0.0
+
+
+register_algorithm("HipApproximateSearch", HipApproximateSearch)
+register_algorithm("HipIVFFlat", HipApproximateSearch)
+register_indexer("HipIVFIndexer", HipIVFIndexer)
+register_indexer("HipFactoryIndexer", HipIVFIndexer)
+register_searcher("HipIVFSearcher", HipIVFSearcher)
