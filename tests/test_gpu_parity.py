@@ -130,8 +130,11 @@ CASES = [
     (300, 50, 17, 10, "l2", "gauss"),
     (5000, 128, 64, 10, "ip", "gauss"),
     (4097, 33, 9, 64, "l2", "gauss"),
-    (3000, 200, 11, 5, "l2", "gauss"),      # D > 128: exhaustive exact kernel
+    (3000, 200, 11, 5, "l2", "gauss"),      # small N: exhaustive exact kernel
     (2000, 768, 4, 10, "ip", "gauss"),
+    (40000, 200, 100, 10, "l2", "gauss"),   # D > 128: K-loop MFMA scan
+    (36000, 768, 80, 10, "ip", "gauss"),
+    (50000, 384, 70, 5, "l2", "gauss"),
     (40000, 128, 200, 10, "l2", "gauss"),   # MFMA scan path
     (40000, 128, 200, 10, "ip", "gauss"),
     (50000, 50, 130, 10, "ip", "glove"),
@@ -168,13 +171,13 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     # the bin select needs the superbins (two per >=512-row chunk) to outnumber k four to one
-    if n >= 32768 and nq >= 64 and d <= 128 and (n + 511) // 512 >= 2 * k:
+    if n >= 32768 and nq >= 64 and (n + 511) // 512 >= 2 * k:
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st
     else:
         assert st["last_path_name"] == "exact_scan", st
     # the forced other path must give the same bits
-    if d <= 128 and n >= 8192 and k * 4 <= n // 512:
+    if n >= 8192 and k * 4 <= n // 512:
         idx.set_option("force_path", 2 if st["last_path_name"] == "exact_scan" else 1)
         D2, I2 = idx.search(Q, k)
         np.testing.assert_array_equal(I2, Io)

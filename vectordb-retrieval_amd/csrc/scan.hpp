@@ -269,6 +269,142 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     }
 }
 
+// ---- K-loop scan for D > 128 (e.g. 384 / 768-dim embeddings) -------------------------------------------
+// Same inputs, outputs and bin semantics as scan_kernel, but the query fragments no longer fit in registers,
+// so the contraction is tiled like a GEMM: workgroup = 8 waves = (corpus chunk) x (256-query tile); wave w owns
+// ONE 32-query column block and ALL 8 row tiles of the current half span (8 x 16 accumulator registers).
+// Per 64-dim K-step the half-span's A panels (32 KiB) arrive in LDS by DMA (double buffered) and are shared
+// by the 8 waves; each wave streams its own B fragments (4 x 1 KiB per K-step) straight from L2 into
+// registers one K-step ahead.  After the K loop the 128 scores per lane go through the same 3-op select;
+// two half-span passes complete a 256-row bin per lane half.  VALU per MFMA is ~1, so this kernel is bound by
+// the matrix pipe and the LDS fragment reads (36 KiB per 32 MFMAs per wave).
+struct ScanKloopExtra {
+    int ksteps;  // 16-dim k-steps, multiple of 4
+};
+
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
+    constexpr int NWAVES = 8, HT = 8;                       // waves, tiles per half span
+    constexpr int kStageVec = HT * 4 * 64;                  // 16-byte vectors per K-step stage (32 KiB)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStageVec * 16];
+    auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
+
+    const int b = blockIdx.x;
+    const int x = b & 7, j = b >> 3;
+    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+    const int chunk = x + 8 * ci;
+    if (chunk >= a.nchunks) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int KS = ex.ksteps, nK = KS / 4;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 32) + wave * 32;
+    const float cs = a.info->cs;
+    const half8 *qp = a.qpanels + (size_t)(q0 / 32) * KS * 64 + lane;   // this wave's B panel
+
+    const int64_t span0 = (int64_t)chunk * a.spans_per_chunk;
+    int64_t span1 = span0 + a.spans_per_chunk;
+    if (span1 > a.nspans) span1 = a.nspans;
+    const int npass = (int)(span1 - span0) * 2;
+    const int nsteps = npass * nK;                          // K-steps over the whole chunk
+
+    const float INF = __builtin_inff();
+    float NEG_INF = -INF;
+    asm volatile("" : "+v"(NEG_INF));
+    unsigned idmask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(idmask));
+    float m1 = INF, m2 = INF, M1 = INF, M2 = INF;
+    int Ms = 0;
+
+    auto stage_issue = [&](int step, int buf) {             // A panels of K-step `step` -> LDS buffer
+        const int pass = step / nK, kk = step - pass * nK;
+        const int64_t tile0 = (span0 + (pass >> 1)) * kTilesPerSpan + (pass & 1) * HT;
+        half8 *dst = lds_a(buf);
+#pragma unroll
+        for (int i = 0; i < (HT * 4) / NWAVES; ++i) {
+            const int p = wave + i * NWAVES;                // piece = (tile t, k-step ks)
+            const int t = p >> 2, ks = p & 3;
+            const half8 *g = a.panels + ((size_t)(tile0 + t) * KS + (kk * 4 + ks)) * 64 + lane;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
+                reinterpret_cast<__attribute__((address_space(3))) void *>(
+                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, 0, 0);
+        }
+    };
+
+    float16v acc[HT];
+    half8 bcur[4], bnext[4];
+    stage_issue(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bnext[ks] = qp[(size_t)ks * 64];
+    __syncthreads();
+
+    int step = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int64_t span = span0 + (pass >> 1);
+        const int half = pass & 1;
+        // accumulators start from the bias of their rows: row = 512*span + 256*h + 16*(8*half + t) + r
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            const float4 *bp = reinterpret_cast<const float4 *>(a.bias + span * kSpanRows + h * kBinRows +
+                                                                (half * HT + t) * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = bp[g];
+                acc[t][4 * g + 0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
+                acc[t][4 * g + 1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
+                acc[t][4 * g + 2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
+                acc[t][4 * g + 3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
+            }
+        }
+        for (int kk = 0; kk < nK; ++kk, ++step) {
+            const int buf = step & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
+            if (step + 1 < nsteps) {
+                stage_issue(step + 1, buf ^ 1);
+                const int kn = (kk + 1 == nK) ? 0 : kk + 1;  // B repeats every pass
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bnext[ks] = qp[(size_t)(kn * 4 + ks) * 64];
+            }
+            const half8 *A = lds_a(buf);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    const half8 af = A[(t * 4 + ks) * 64 + lane];
+                    if (ABL != 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bcur[ks], acc[t], 0, 0, 0);
+                }
+            __syncthreads();  // next stage landed (vmcnt(0) drained by hipcc) and this buffer is free again
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            const unsigned id0 = (unsigned)((half * HT + t) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = pack_score(acc[t][r], idmask, id0 + r);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
+                m1 = fast_min(m1, v, NEG_INF);
+            }
+        }
+        if (half == 1) {
+            const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + (lane & 31);
+            a.bin_m1[o] = m1;
+            a.bin_m2[o] = m2;
+            M2 = __builtin_fminf(__builtin_amdgcn_fmed3f(M1, M2, m1), m2);
+            if (m1 < M1) Ms = (int)span;
+            M1 = __builtin_fminf(M1, m1);
+            m1 = INF;
+            m2 = INF;
+        }
+    }
+    const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
+    a.sb_m1[so] = M1;
+    a.sb_m2[so] = M2;
+    a.sb_span[so] = Ms;
+}
+
 // ---- select: per query, turn the bin minima into an exact-refine work list --------------------------
 // One wave per query.  tau = k-th smallest superbin minimum (bitwise bisection on the sortable key);
 // That = tau + 2*eps.  Every score <= That is either a bin minimum (-> candidate row) or lives in a bin

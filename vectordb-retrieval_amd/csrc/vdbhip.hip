@@ -176,7 +176,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
         frexpf(h->absmax, &e);
         h->sx = ldexpf(1.f, 14 - e);  // absmax*sx in [8192, 16384)
     }
-    const bool dims_ok = D <= 16 * kMaxKSteps;
+    const bool dims_ok = D <= 4096;
     if (dims_ok && !h->nonfinite) {
         const int64_t ntiles = h->Npad / kTileRows;
         h->panels.reserve((size_t)ntiles * h->ksteps * 64 * sizeof(half8));
@@ -247,7 +247,11 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
 }
 
 void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
-    if (h->ksteps == 4)
+    if (h->ksteps > kMaxKSteps) {  // D > 128
+        sa.nqtiles = (int)(Qpad / 256);
+        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
+        scan_kloop_kernel<0><<<dim3(grid), dim3(512), 0, st>>>(sa, ScanKloopExtra{h->ksteps});
+    } else if (h->ksteps == 4)
         launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st);
     else
         launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st);
@@ -597,7 +601,7 @@ int vdb_create(int dim, int metric, int device, vdb_handle *out) {
         h->device = device;
         h->dim = dim;
         h->D4 = (dim + 3) / 4 * 4;
-        h->ksteps = dim <= 64 ? 4 : 8;
+        h->ksteps = dim <= 64 ? 4 : (dim <= 128 ? 8 : (dim + 63) / 64 * 4);  // D > 128: K-loop kernel, 64-dim steps
         h->metric = metric;
         *out = h;
     });
