@@ -42,6 +42,7 @@ WORKLOADS = {
     "sift1m": (1_000_000, 128, 10_000, 10, "l2", "sift_like"),
     "gaussian1m": (1_000_000, 128, 10_000, 10, "l2", "gaussian"),
     "glove1.2m": (1_200_000, 50, 10_000, 10, "ip", "glove_like"),
+    "marco2m": (2_000_000, 768, 10_000, 10, "ip", "gaussian"),   # MS MARCO-shaped shard slice (config 5 is 12.5M/GPU)
     "smoke": (10_000, 128, 100, 10, "l2", "random_reference"),
 }
 
@@ -194,7 +195,7 @@ def main() -> None:
                                f"brute-force exact k-NN, inputs resident in HBM",
                    "rows_per_gpu": n, "dim": d, "queries": nq, "k": k, "metric": metric,
                    "sharding": "none" if world == 1 else f"row-sharded x{world}, RCCL all-gather of partial top-k"},
-        "roofline": {"bound": "mfma", "kernel": "scan_kernel<%d>" % (4 if d <= 64 else 8),
+        "roofline": {"bound": "mfma", "kernel": ("scan_kernel<%d>" % (4 if d <= 64 else 8)) if d <= 128 else "scan_kloop_kernel",
                      "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                      "kernel_ms": round(scan_ms, 4), "pipeline_ms": round(float(st["last_total_ms"]), 4),

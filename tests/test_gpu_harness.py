@@ -1,0 +1,65 @@
+"""End-to-end plugin plumbing through a reference-shaped config (the idiom of the reference's
+tests/test_benchmark_runner_modular.py:9-65): indexer_ref/searcher_ref resolution, result keys, counts."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = {
+    "seed": 42, "topk": 5, "n_queries": 5, "query_batch_size": 2,
+    "indexers": {"hip_bf_l2": {"type": "HipBruteForceIndexer", "metric": "l2"},
+                 "hip_ivf_l2": {"type": "HipIVFIndexer", "index_type": "IVF4,Flat", "metric": "l2", "nprobe": 4}},
+    "searchers": {"hip_linear_l2": {"type": "HipLinearSearcher", "metric": "l2"},
+                  "hip_ivf_search": {"type": "HipIVFSearcher", "metric": "l2"}},
+    "algorithms": {"exact": {"indexer_ref": "hip_bf_l2", "searcher_ref": "hip_linear_l2", "metric": "l2"},
+                   "exact_hip": {"type": "HipExactSearch", "metric": "l2"},
+                   "ivf_flat": {"indexer_ref": "hip_ivf_l2", "searcher_ref": "hip_ivf_search", "metric": "l2"}},
+    "datasets": [{"name": "random", "metric": "l2",
+                  "dataset_options": {"dimensions": 3, "train_size": 32, "test_size": 5, "ground_truth_k": 5,
+                                      "seed": 7}}],
+}
+
+
+def test_reference_shaped_config_end_to_end():
+    from vdbhip import harness
+
+    res = harness.run_benchmark(CONFIG)["random"]
+    assert set(res) == {"exact", "exact_hip", "ivf_flat"}
+    for name, m in res.items():
+        for key in ("qps", "mean_query_time_ms", "total_query_time_s", "build_time_s", "index_memory_mb", "recall@1",
+                    "n_train", "n_test", "dimensions", "topk", "parameters"):
+            assert key in m, (name, key)
+        assert m["n_train"] == 32 and m["n_test"] == 5 and m["topk"] == 5 and m["used_batch_api"]
+        assert m["recall@1"] == 1.0 and m["recall"] == 1.0      # exact; IVF probes all 4 lists
+        json.dumps(m)
+    assert res["exact"]["parameters"]["indexer"]["type"] == "HipBruteForceIndexer"
+    assert res["exact_hip"]["operations_per_query"] == 32
+
+
+def test_harness_swallows_valueerror_like_the_reference():
+    """A ValueError from batch_search silently degrades to per-query search (experiment_runner.py:442-455):
+    the reason the HIP plugins only ever raise RuntimeError at search time."""
+    from vdbhip import BaseAlgorithm, harness
+
+    class Flaky(BaseAlgorithm):
+        def build_index(self, vectors, metadata=None):
+            self.v = vectors
+            self.index_built = True
+
+        def batch_search(self, queries, k=10):
+            raise ValueError("boom")
+
+        def search(self, query, k=10):
+            d = np.linalg.norm(self.v - query, axis=1)
+            i = np.argsort(d)[:k]
+            return d[i], i
+
+    rng = np.random.default_rng(0)
+    X, Q = rng.standard_normal((20, 3)).astype(np.float32), rng.standard_normal((4, 3)).astype(np.float32)
+    gt = np.stack([np.argsort(np.linalg.norm(X - q, axis=1))[:3] for q in Q])
+    out = harness.run_single_algorithm(Flaky("f", 3), X, Q, gt, 3)
+    assert out["metrics"]["used_batch_api"] is False and out["metrics"]["recall@1"] == 1.0

@@ -1,0 +1,178 @@
+"""Minimal experiment harness with the reference's call contract and result keys.
+
+Mirrors the part of ExperimentRunner that drives the hot path (src/experiments/experiment_runner.py:259-488):
+  build_index(train) timed -> batch_search(test[cursor:end], k) per query batch, wall-clock timed with
+  time.time() (:431-433), batch = all queries when query_batch_size == 0 (:424), fallback to per-query
+  search() on (AttributeError, NotImplementedError, TypeError, ValueError) (:442-455), indices normalised to
+  (n,k) int64 with -1 padding (:381-418), qps = n_queries / total_query_time (:464), recall@{1,10,100} with
+  k <= topk (evaluation.py:23-29, 47-50).
+and the YAML shapes of configs/*.yaml (runner.py:95-155, 274-299): top-level `indexers`, `searchers`,
+`algorithms`, `datasets[]`; an algorithm entry is {type, metric, ...kwargs} or {indexer_ref, searcher_ref}.
+Only synthetic `random` datasets (dataset.py:473-504 recipe) are generated here -- downloads are out of scope.
+"""
+from __future__ import annotations
+
+import copy
+import time
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import datasets
+from .metrics import recall_at_k
+from .plugin_api import BaseAlgorithm, get_algorithm_instance
+
+
+def resolve_modular_components(algorithms: Dict[str, Any], indexers: Dict[str, Any], searchers: Dict[str, Any]):
+    """indexer_ref / searcher_ref -> inline dicts; default type 'Composite' (runner.py:274-299)."""
+    out = {}
+    for name, cfg in algorithms.items():
+        cfg = copy.deepcopy(cfg)
+        if "indexer_ref" in cfg or "searcher_ref" in cfg:
+            iref, sref = cfg.pop("indexer_ref", None), cfg.pop("searcher_ref", None)
+            if iref not in indexers:
+                raise ValueError(f"Unknown indexer_ref '{iref}' for algorithm '{name}'")
+            if sref not in searchers:
+                raise ValueError(f"Unknown searcher_ref '{sref}' for algorithm '{name}'")
+            cfg["indexer"] = copy.deepcopy(indexers[iref])
+            cfg["searcher"] = copy.deepcopy(searchers[sref])
+            cfg.setdefault("type", "Composite")
+        out[name] = cfg
+    return out
+
+
+def normalize_batch_indices(batch_result: Any, expected_rows: int, expected_k: int) -> np.ndarray:
+    """experiment_runner.py:381-418."""
+    if isinstance(batch_result, tuple):
+        if len(batch_result) != 2:
+            raise ValueError("batch_search must return (distances, indices)")
+        batch_result = batch_result[1]
+    if isinstance(batch_result, list):
+        out = np.full((expected_rows, expected_k), -1, dtype=np.int64)
+        for r, row in enumerate(batch_result[:expected_rows]):
+            row = np.asarray(row)
+            n = min(row.size, expected_k)
+            out[r, :n] = row[:n]
+        return out
+    arr = np.asarray(batch_result)
+    if arr.ndim == 1:
+        arr = arr.reshape(1, -1)
+    if arr.ndim != 2:
+        raise ValueError("batch_search returned array with unexpected shape")
+    if arr.shape[0] != expected_rows:
+        if expected_rows == 1 and arr.shape[0] == expected_k:
+            arr = arr.reshape(1, -1)
+        else:
+            raise ValueError(f"batch_search returned {arr.shape[0]} rows, expected {expected_rows}")
+    if arr.shape[1] < expected_k:
+        pad = np.full((expected_rows, expected_k), -1, dtype=np.int64)
+        pad[:, :arr.shape[1]] = arr
+        arr = pad
+    elif arr.shape[1] > expected_k:
+        arr = arr[:, :expected_k]
+    return arr.astype(np.int64, copy=False)
+
+
+def run_single_algorithm(algorithm: BaseAlgorithm, train: np.ndarray, test: np.ndarray, ground_truth: np.ndarray,
+                         topk: int, query_batch_size: int = 0, dataset: str = "random") -> Dict[str, Any]:
+    t0 = time.time()
+    algorithm.build_index(train)
+    build_time = time.time() - t0
+    n = len(test)
+    indices = np.full((n, topk), -1, dtype=np.int64)
+    query_times = np.zeros(n)
+    total = 0.0
+    used_batch = False
+    batch = n if query_batch_size == 0 else min(query_batch_size, n)
+    if n:
+        try:
+            cur = 0
+            while cur < n:
+                end = min(cur + batch, n)
+                t0 = time.time()
+                res = algorithm.batch_search(test[cur:end], k=topk)
+                dt = time.time() - t0
+                indices[cur:end] = normalize_batch_indices(res, end - cur, topk)
+                query_times[cur:end] = dt / max(end - cur, 1)
+                total += dt
+                cur = end
+            used_batch = True
+        except (AttributeError, NotImplementedError, TypeError, ValueError):
+            indices.fill(-1)
+            query_times.fill(0.0)
+            total = 0.0
+    if not used_batch:
+        for i, q in enumerate(test):
+            t0 = time.time()
+            _, idx = algorithm.search(q, k=topk)
+            dt = time.time() - t0
+            query_times[i] = dt
+            indices[i] = idx
+            total += dt
+    total = max(total, query_times.sum())
+    mem = getattr(algorithm, "get_memory_usage", lambda: None)()
+    metrics: Dict[str, Any] = {
+        "algorithm": algorithm.get_name(), "parameters": algorithm.get_parameters(), "dataset": dataset,
+        "n_train": int(train.shape[0]), "n_test": int(n), "dimensions": int(train.shape[1]), "topk": int(topk),
+        "build_time_s": float(build_time), "total_query_time_s": float(total),
+        "mean_query_time_ms": float(total / max(n, 1) * 1000.0), "qps": float(n / total) if total > 0 else 0.0,
+        "index_memory_mb": float(mem) if mem else float(train.nbytes) / 2 ** 20, "used_batch_api": used_batch,
+    }
+    ops = algorithm.get_operations()
+    if ops.get("ndis") and n:
+        metrics["operations_per_query"] = ops["ndis"] / n     # picked up by evaluation.py:79-87 when present
+    for k in (1, 10, 100):
+        if k <= topk and ground_truth is not None:
+            metrics[f"recall@{k}"] = float(recall_at_k(ground_truth, indices, k))
+    if ground_truth is not None:
+        metrics["recall"] = metrics.get(f"recall@{min(100, topk)}", max(
+            (v for kk, v in metrics.items() if kk.startswith("recall@")), default=0.0))
+    return {"metrics": metrics, "indices": indices}
+
+
+def run_benchmark(config: Dict[str, Any]) -> Dict[str, Dict[str, Any]]:
+    """Run every algorithm of a reference-shaped config on its `random` datasets; returns
+    {dataset: {algorithm: metrics}}."""
+    indexers, searchers = config.get("indexers", {}) or {}, config.get("searchers", {}) or {}
+    base_algos = config.get("algorithms", {}) or {}
+    results: Dict[str, Dict[str, Any]] = {}
+    for entry in config.get("datasets", [{"name": "random"}]):
+        name = entry.get("name", "random")
+        if name != "random":
+            raise ValueError(f"dataset '{name}' needs files that are not available offline; only 'random' is generated")
+        opts = entry.get("dataset_options", {}) or {}
+        dim, ntrain = int(opts.get("dimensions", 128)), int(opts.get("train_size", 10000))
+        ntest, gtk = int(opts.get("test_size", 1000)), int(opts.get("ground_truth_k", 100))
+        train, test = datasets.random_reference(dim, ntrain, ntest, int(opts.get("seed", 42)))
+        gt = np.stack([np.argsort(np.linalg.norm(train - q, axis=1))[:gtk] for q in test]).astype(np.int32)
+        topk = int(entry.get("topk", config.get("topk", 10)))
+        nq = int(entry.get("n_queries", config.get("n_queries", ntest)))
+        qbs = int(entry.get("query_batch_size", config.get("query_batch_size", 0)))
+        if nq < ntest:   # experiment_runner.py:79, 138-153
+            state = np.random.get_state()
+            np.random.seed(int(config.get("seed", 42)))
+            pick = np.random.choice(ntest, nq, replace=False)
+            np.random.set_state(state)
+            test, gt = test[pick], gt[pick]
+        algos = copy.deepcopy(base_algos)
+        for an, override in (entry.get("algorithms", {}) or {}).items():
+            algos.setdefault(an, {}).update(override or {})
+        metric = entry.get("metric")
+        for cfg in algos.values():          # the dataset metric is forced onto every algorithm (runner.py:117-118)
+            if metric:
+                cfg["metric"] = metric
+        algos = resolve_modular_components(algos, indexers, searchers)
+        results[name] = {}
+        for an, cfg in algos.items():
+            cfg = copy.deepcopy(cfg)
+            atype = cfg.pop("type")
+            algo = get_algorithm_instance(atype, dim, name=an, **cfg)
+            results[name][an] = run_single_algorithm(algo, train, test, gt, topk, qbs, name)["metrics"]
+    return results
+
+
+def load_config(path: str) -> Dict[str, Any]:
+    import yaml
+
+    with open(path) as f:
+        return yaml.safe_load(f)
