@@ -59,7 +59,39 @@ def test_injected_centroids_bit_exact(vdb, oracle, metric, n, d, nlist, nq, k):
     np.testing.assert_array_equal(D, Db)
     st = idx.stats()
     assert st["last_path_name"] == "ivf" and st["nlist"] == nlist
+    # the exact list scan (force_path=1) and the list-major MFMA scan must agree bit for bit
+    idx.set_nprobe(16)
+    D1, I1 = idx.search(Q, k)
+    idx.set_option("force_path", 1)
+    D2, I2 = idx.search(Q, k)
+    np.testing.assert_array_equal(I1, I2)
+    np.testing.assert_array_equal(D1, D2)
     idx.close()
+
+
+def test_list_major_mfma_scan_is_used_and_exact(vdb, oracle):
+    X, Q = _data(200000, 128, 1000, 21, clustered=False)
+    nlist = 256
+    C = X[np.random.default_rng(2).choice(len(X), nlist, replace=False)].copy()
+    for metric in ("l2", "ip"):
+        idx = vdb.IVFFlatIndex(128, nlist, metric, 0)
+        idx.set_centroids(C)
+        idx.add(X)
+        lor = idx.assignment()
+        for nprobe in (8, 64):
+            idx.set_nprobe(nprobe)
+            D, I = idx.search(Q, 10)
+            st = idx.stats()
+            Do, Io = oracle.ivf_search(X, C, lor, Q, 10, nprobe, metric)
+            np.testing.assert_array_equal(I, Io)
+            np.testing.assert_array_equal(D, Do)
+            assert st["last_candidates"] > 0, st            # the MFMA path served the batch
+            assert st["last_fallback_queries"] < 50, st
+        idx.set_option("list_cap", 1)                       # every query overflows -> exact list scan per query
+        D, I = idx.search(Q, 10)
+        np.testing.assert_array_equal(I, Io)
+        assert idx.stats()["last_fallback_queries"] == len(Q)
+        idx.close()
 
 
 def test_small_lists_padding_and_errors(vdb, oracle):

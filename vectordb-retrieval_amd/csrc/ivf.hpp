@@ -19,6 +19,7 @@ struct IvfScanArgs {
     int64_t nq;
     int nprobe;
     int S;                     // waves per query; wave s takes probes s, s+S, ...
+    const int32_t *only_flagged; // optional [nq]: process only queries whose flag is set (fallback pass)
     float *D;                  // S == 1: final rows
     int64_t *I;
     double *pkeys;             // else partials [nq][S][k]
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(IvfScanArgs a) {
     if (u >= a.nq * a.S) return;
     const int64_t q = u / a.S;
     const int split = (int)(u - q * a.S);
+    if (a.only_flagged && !a.only_flagged[q]) return;
     const float *qptr = a.c.Q + (size_t)q * a.c.D4;
     WaveTopK<KPL> tk;
     tk.init(a.c.k);

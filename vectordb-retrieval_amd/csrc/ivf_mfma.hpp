@@ -1,0 +1,278 @@
+// ivf_mfma.hpp -- list-major IVF-Flat scan on the matrix cores.
+//
+// The query-major exact list scan (ivf.hpp) re-reads every probed list once per query: at nprobe = 128 that is
+// 640 GB of L2/HBM traffic per 10k-query batch.  Here the (query -> lists) relation is inverted on the device
+// into (list -> query slots), so each list's fp16 panels are streamed ONCE per group of up to 512 queries and
+// multiplied against them with the same scan_kernel as the flat index (ITEMS mode, 64-row bins).  A per-query
+// select over the bins of its probed lists nominates candidate rows / bins to re-scan, and the exact float64
+// refine kernel produces the final answer: the result is bit-identical to the exact list scan.
+//
+// Panel space: every list is padded to whole 512-row spans; span_row0 / span_valid map a panel span back to
+// the permuted row range it covers.
+#pragma once
+#include "common.hpp"
+#include "prep.hpp"
+#include "scan.hpp"
+
+namespace vdb {
+
+constexpr int kIvfBT = 4;                      // tiles per level-1 bin: 64-row bins
+constexpr int kIvfBPS = kTilesPerSpan / kIvfBT;
+
+// ---- build: panels + bias over the list-padded panel space ------------------------------------------
+__global__ __launch_bounds__(256) void ivf_build_panels_kernel(const float *__restrict__ X, int D, int D4, int ksteps,
+                                                               int64_t ntiles, float sx,
+                                                               const int32_t *__restrict__ span_row0,
+                                                               const int32_t *__restrict__ span_valid,
+                                                               half8 *__restrict__ panels, IndexStats *st) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ksteps);
+    const int64_t tile = tk / ksteps;
+    int inexact = 0;
+    if (tile < ntiles) {
+        const int rho = lane & 31, kh = lane >> 5;
+        const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+        const int64_t span = tile / kTilesPerSpan;
+        const int t = (int)(tile - span * kTilesPerSpan);
+        const int local = h * kBinRows + t * 16 + r;
+        const bool valid = local < span_valid[span];
+        const int64_t row = (int64_t)span_row0[span] + local;
+        const int d0 = ks * 16 + kh * 8;
+        half8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = d0 + j;
+            float v = 0.f;
+            if (valid && d < D) v = X[(size_t)row * D4 + d] * sx;
+            const _Float16 hv = (_Float16)v;
+            inexact |= ((float)hv != v);
+            out[j] = hv;
+        }
+        panels[gid] = out;
+    }
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+}
+
+__global__ __launch_bounds__(256) void ivf_build_bias_kernel(const float *__restrict__ xnorm2, int64_t nspans, int metric,
+                                                             const int32_t *__restrict__ span_row0,
+                                                             const int32_t *__restrict__ span_valid,
+                                                             float *__restrict__ bias) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nspans * kSpanRows) return;
+    const int64_t span = i / kSpanRows;
+    const int local = (int)(i - span * kSpanRows);
+    bias[i] = (local < span_valid[span]) ? (metric == 0 ? xnorm2[span_row0[span] + local] : 0.f) : kPadBias;
+}
+
+// ---- per batch: invert (query, probe) -> (list, slot) ---------------------------------------------------
+struct IvfPlan {          // device-resident scalars written by ivf_plan_kernel
+    int32_t n_items;
+    int32_t n_slots;
+    int32_t n_bins;
+    int32_t overflow;     // plan did not fit the buffers: the batch takes the exact list scan
+};
+
+__global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restrict__ probes, int64_t n, int nlist,
+                                                        int32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = probes[i];
+    if (l >= 0 && l < nlist) atomicAdd(&cnt[l], 1);
+}
+
+// one thread: slot ranges (padded to `group`), work items (list x group of slots), output bin blocks
+__global__ void ivf_plan_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ list_pspan0, int nlist,
+                                int group, int max_items, int max_slots, int max_bins, int32_t *__restrict__ slot_off,
+                                int32_t *__restrict__ list_item0, int32_t *__restrict__ item_list,
+                                int32_t *__restrict__ item_slot0, int32_t *__restrict__ item_bin0, IvfPlan *plan) {
+    int slots = 0, items = 0, bins = 0, overflow = 0;
+    for (int l = 0; l < nlist; ++l) {
+        slot_off[l] = slots;
+        list_item0[l] = items;
+        const int c = cnt[l];
+        const int spans = list_pspan0[l + 1] - list_pspan0[l];
+        if (c > 0 && spans > 0) {
+            const int g = (c + group - 1) / group;
+            for (int j = 0; j < g; ++j) {
+                if (items < max_items) {
+                    item_list[items] = l;
+                    item_slot0[items] = slots + j * group;
+                    item_bin0[items] = bins;
+                } else {
+                    overflow = 1;
+                }
+                ++items;
+                bins += spans * 2 * kIvfBPS;
+            }
+            slots += g * group;
+        }
+    }
+    slot_off[nlist] = slots;
+    list_item0[nlist] = items;
+    if (slots > max_slots || bins > max_bins || items > max_items) overflow = 1;
+    plan->n_items = overflow ? 0 : items;
+    plan->n_slots = slots;
+    plan->n_bins = bins;
+    plan->overflow = overflow;
+}
+
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
+                                                          int nlist, const int32_t *__restrict__ slot_off,
+                                                          const int32_t *__restrict__ list_pspan0,
+                                                          int32_t *__restrict__ cursor, const IvfPlan *plan,
+                                                          int32_t *__restrict__ slot_query, int32_t *__restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * nprobe) return;
+    const int64_t l = probes[i];
+    int slot = -1;
+    // (an empty list owns no slots: probing it contributes nothing)
+    if (!plan->overflow && l >= 0 && l < nlist && list_pspan0[l + 1] > list_pspan0[l]) {
+        slot = slot_off[l] + atomicAdd(&cursor[l], 1);
+        slot_query[slot] = (int32_t)(i / nprobe);
+    }
+    slot_of[i] = slot;
+}
+
+// fp16 B-fragment panels of the gathered query slots (slot_query = -1 -> zero column)
+__global__ __launch_bounds__(256) void ivf_qpanels_kernel(const float *__restrict__ Q, int D, int ksteps,
+                                                          const int32_t *__restrict__ slot_query, const IvfPlan *plan,
+                                                          const QueryBatchInfo *__restrict__ info,
+                                                          half8 *__restrict__ qpanels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ksteps);
+    const int64_t tile = tk / ksteps;
+    if (tile * 32 >= plan->n_slots) return;
+    const float bs = info->bscale;
+    const int q = slot_query[tile * 32 + (lane & 31)];
+    const int d0 = ks * 16 + (lane >> 5) * 8;
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = d0 + j;
+        float v = 0.f;
+        if (q >= 0 && d < D) v = Q[(size_t)q * D + d] * bs;
+        out[j] = (_Float16)v;
+    }
+    qpanels[gid] = out;
+}
+
+// ---- select over the bins of a query's probed lists ----------------------------------------------------
+struct IvfSelectArgs {
+    const float *bin_m1, *bin_m2;
+    const float *eps;
+    const QueryBatchInfo *info;
+    const IvfPlan *plan;
+    const int64_t *probes;        // [nq][nprobe]
+    const int32_t *slot_of;       // [nq][nprobe]
+    const int32_t *slot_off, *list_item0, *item_bin0, *list_pspan0, *span_row0, *span_valid;
+    int64_t nq;
+    int nprobe, group, k, cand_cap, rescan_cap, max_entries;
+    int32_t *cand_rows, *rescan_rows, *counts, *fallback;
+    unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
+};
+
+// one wave per query; the bin minima of the query live in LDS (max_entries floats + descriptors per wave)
+__global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 2 waves: 64 KiB of LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char ivf_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 2 + wave));
+    if (q >= a.nq) return;
+    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * a.max_entries * 2;
+    unsigned *desc = vals + a.max_entries;    // (probe << 16) | entry-in-item
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    bool fb = a.plan->overflow || a.info->force_fallback;
+    int E = 0;                                 // wave-uniform number of entries gathered
+    if (!fb) {
+        for (int p = 0; p < a.nprobe; ++p) {
+            const int64_t l = a.probes[(size_t)q * a.nprobe + p];
+            const int slot = a.slot_of[(size_t)q * a.nprobe + p];
+            if (l < 0 || slot < 0) continue;
+            const int rel = slot - a.slot_off[l];
+            const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
+            const int nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * kIvfBPS;
+            if (E + nb > a.max_entries || nb > 65535) {
+                fb = true;
+                break;
+            }
+            const float *src = a.bin_m1 + (size_t)a.item_bin0[item] * a.group + col;
+            for (int e = lane; e < nb; e += 64) {
+                vals[E + e] = sortable_u32(src[(size_t)e * a.group]);
+                desc[E + e] = ((unsigned)p << 16) | (unsigned)e;
+            }
+            E += nb;
+        }
+    }
+    if (!fb && E < a.k) fb = true;            // not enough bins to bound the k-th neighbour: exact list scan
+    int ncand = 0, nres = 0;
+    if (!fb) {
+        unsigned ans = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = ans | ((1u << bit) - 1u);
+            int cnt = 0;
+            for (int e = lane; e < E; e += 64) cnt += (vals[e] <= trial) ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (cnt < a.k) ans |= (1u << bit);
+        }
+        const float that = unsortable_f32(ans) + 2.0f * a.eps[q];
+        if (!(that < 0.9e38f)) fb = true;
+        int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
+        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+        for (int base = 0; base < E && !fb; base += 64) {
+            const int e = base + lane;
+            bool cand = false, resc = false;
+            int row0 = 0, row1 = 0;
+            float m1 = 0.f;
+            if (e < E) {
+                m1 = unsortable_f32(vals[e]);
+                if (m1 <= that) {
+                    const unsigned d = desc[e];
+                    const int p = (int)(d >> 16), ei = (int)(d & 0xFFFFu);
+                    const int64_t l = a.probes[(size_t)q * a.nprobe + p];
+                    const int rel = a.slot_of[(size_t)q * a.nprobe + p] - a.slot_off[l];
+                    const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
+                    const float m2 = a.bin_m2[((size_t)a.item_bin0[item] + ei) * a.group + col];
+                    const int span_local = ei / (2 * kIvfBPS), hh = (ei / kIvfBPS) & 1, bt = ei % kIvfBPS;
+                    const int pspan = a.list_pspan0[l] + span_local;
+                    row0 = a.span_row0[pspan] + hh * kBinRows + bt * (kIvfBT * 16);
+                    row1 = row0 + kIvfBT * 16;
+                    const int end = a.span_row0[pspan] + a.span_valid[pspan];
+                    if (row1 > end) row1 = end;
+                    resc = m2 <= that;
+                    cand = !resc;
+                }
+            }
+            const unsigned long long cm = __ballot(cand), rm = __ballot(resc);
+            if (cand) {
+                const int pos = ncand + __popcll(cm & lt_mask);
+                if (pos < a.cand_cap) cr[pos] = row0 + (int)(__float_as_uint(m1) & 0xFFu);
+            }
+            if (resc) {
+                const int pos = nres + __popcll(rm & lt_mask);
+                if (pos < a.rescan_cap) {
+                    rr[2 * pos] = row0;
+                    rr[2 * pos + 1] = row1;
+                }
+            }
+            ncand += __popcll(cm);
+            nres += __popcll(rm);
+        }
+        if (ncand > a.cand_cap || nres > a.rescan_cap) fb = true;
+    }
+    if (lane == 0) {
+        a.counts[2 * q] = fb ? 0 : ncand;
+        a.counts[2 * q + 1] = fb ? 0 : nres;
+        a.fallback[q] = fb ? 1 : 0;
+        if (fb) {
+            atomicAdd(&a.stat_counters[2], 1ull);
+        } else {
+            atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
+            atomicAdd(&a.stat_counters[1], (unsigned long long)nres);
+        }
+    }
+}
+
+}  // namespace vdb

@@ -98,7 +98,7 @@ struct RefineListArgs {
     RefineCommon c;
     int64_t nq;
     const int32_t *cand_rows;   // [nq][cand_cap] local row numbers
-    const int32_t *rescan_rows; // [nq][rescan_cap] first row of 256-row bins
+    const int32_t *rescan_rows; // [nq][rescan_cap][2] row ranges [row0,row1) of the bins to re-scan
     const int32_t *counts;      // [nq][2] {n_cand, n_rescan}
     const int32_t *fallback;    // [nq] 1 -> handled by the exhaustive pass
     int cand_cap;
@@ -130,13 +130,10 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
         valid = valid && row < a.c.N;
         uint64_t key = ~0ull;
         if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
-        tk.offer(key, a.c.id_base + row, valid);
+        tk.offer(key, a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row, valid);
     }
-    const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap;
-    for (int r = 0; r < nres; ++r) {
-        const int64_t row0 = rr[r];
-        scan_rows<KPL>(tk, a.c, qptr, row0, row0 + kBinRows);
-    }
+    const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+    for (int r = 0; r < nres; ++r) scan_rows<KPL>(tk, a.c, qptr, rr[2 * r], rr[2 * r + 1]);
     const size_t o = (size_t)q * a.c.k;
     write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
                     a.pids ? a.pids + o : nullptr);

@@ -37,6 +37,12 @@ struct ScanArgs {
     int nchunks;
     int nqtiles;           // query tiles (64 * NWAVES queries each)
     int64_t Qpad;          // multiple of 512
+    // ---- IVF ("items") mode: one workgroup = (one inverted list) x (one group of 64*NWAVES query slots) ----
+    const int32_t *item_list;    // [items] list id
+    const int32_t *item_slot0;   // [items] first query slot of the group
+    const int32_t *item_bin0;    // [items] first level-1 bin of the item's output block
+    const int32_t *n_items;      // [1]
+    const int32_t *list_pspan0;  // [nlist+1] panel spans of every list (lists are padded to whole spans)
 };
 
 // (score & ~0xFF) | id  -- one v_and_or_b32 when the mask lives in a VGPR (the id is wave-uniform)
@@ -106,29 +112,51 @@ __device__ __forceinline__ void read_phase(const half8 *__restrict__ A_tile, con
 // so that while one wave owns the matrix pipe its partner is on the VALU, instead of both queueing for the
 // same pipe (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Both orders do the same work per stage,
 // so the per-stage barrier keeps the stagger locked.
-template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0>
+// BT: tiles per level-1 bin per lane half (16 -> 256-row bins for the flat index, 4 -> 64-row bins for IVF,
+// whose per-query row count is small); ITEMS: IVF work-item mode (see ScanArgs).
+template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0, int BT = 16, bool ITEMS = false>
 __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KSTEPS * 64;           // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
     constexpr int SPS = kTilesPerSpan / ST;               // stages per span
-    static_assert(kTilesPerSpan % ST == 0 && ST >= 2, "bad stage geometry");
+    constexpr int BPS = kTilesPerSpan / BT;               // level-1 bins per (span, lane half)
+    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && kTilesPerSpan % BT == 0 && BT % ST == 0, "bad geometry");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
     auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
 
-    // ---- block -> (chunk, query tile), XCD aware -------------------------------------------------
-    const int b = blockIdx.x;
-    const int x = b & 7, j = b >> 3;
-    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
-    const int chunk = x + 8 * ci;
-    if (chunk >= a.nchunks) return;
-
+    // ---- block -> (chunk, query tile), XCD aware; or -> IVF work item -----------------------------
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const bool late = (NWAVES >= 2) && (wave >= NWAVES / 2);
-    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;  // first query of this wave
+    int chunk = 0;
+    int64_t q0, span0, span1, out_pitch, out_col;
+    size_t bin_base = 0;                                    // first level-1 bin of this block's output
+    if (ITEMS) {
+        const int it = blockIdx.x;
+        if (it >= *a.n_items) return;
+        const int l = a.item_list[it];
+        span0 = a.list_pspan0[l];
+        span1 = a.list_pspan0[l + 1];
+        q0 = (int64_t)a.item_slot0[it] + wave * 64;        // "queries" are gathered query slots
+        out_pitch = NWAVES * 64;
+        out_col = wave * 64 + (lane & 31);
+        bin_base = (size_t)a.item_bin0[it];
+    } else {
+        const int b = blockIdx.x;
+        const int x = b & 7, j = b >> 3;
+        const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+        chunk = x + 8 * ci;
+        if (chunk >= a.nchunks) return;
+        q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;       // first query of this wave
+        span0 = (int64_t)chunk * a.spans_per_chunk;
+        span1 = span0 + a.spans_per_chunk;
+        if (span1 > a.nspans) span1 = a.nspans;
+        out_pitch = a.Qpad;
+        out_col = q0 + (lane & 31);
+    }
     const float cs = a.info->cs;
 
     // ---- B fragments: resident for the whole chunk ------------------------------------------------
@@ -139,9 +167,6 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KSTEPS + ks) * 64 + lane];
     }
 
-    const int64_t span0 = (int64_t)chunk * a.spans_per_chunk;
-    int64_t span1 = span0 + a.spans_per_chunk;
-    if (span1 > a.nspans) span1 = a.nspans;
     const int nstages = (int)(span1 - span0) * SPS;
 
     const float INF = __builtin_inff();
@@ -189,15 +214,20 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (tid + i * NT < ST * 32)
                 lds_b(buf)[tid + i * NT] = (stage_b[i] >= 0.9e38f) ? kPadBias : stage_b[i] * cs;
     };
-    auto flush_span = [&](int64_t span) {  // two bins per lane column are complete: level 1 out, fold level 2
-        const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + (lane & 31);
+    // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
+    auto flush_bin = [&](int64_t span, int bt) {
+        const size_t bin = ITEMS ? bin_base + (size_t)(((span - span0) * 2 + h) * BPS + bt)
+                                 : (size_t)((span * 2 + h) * BPS + bt);
+        const size_t o = bin * out_pitch + out_col;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             a.bin_m1[o + cb * 32] = m1[cb];
             a.bin_m2[o + cb * 32] = m2[cb];
-            M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
-            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
-            M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+            if (!ITEMS) {
+                M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+                M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+            }
             m1[cb] = INF;
             m2[cb] = INF;
         }
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);  // buf^1 was last read before the previous barrier
             const half8 *A = lds_a(buf);
             const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
-            const unsigned idS = (unsigned)(((st % SPS) * ST) << 4);
+            const int ts0 = (st % SPS) * ST;                 // first tile of this stage inside its span
             read_phase<KSTEPS>(A, B4, fr, cin, lane);
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
@@ -225,10 +255,10 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, idS + t * 16);
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 4));
             }
             __builtin_amdgcn_sched_barrier(0);
-            if ((st % SPS) == SPS - 1) flush_span(span0 + st / SPS);
+            if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);  // BT % ST == 0
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
@@ -242,13 +272,16 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
             const half8 *A = lds_a(buf);
             const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
-            const unsigned idS = (unsigned)(((st % SPS) * ST) << 4);
+            const int ts0 = (st % SPS) * ST;
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, t == 0 ? ((idS + 240u) & 255u) : idS + (t - 1) * 16);
-                if (t == 0 && st > 0 && (st % SPS) == 0) flush_span(span0 + st / SPS - 1);
+                // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
+                const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 4));
+                if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
+                    flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
             }
@@ -256,9 +289,10 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
-        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, 240u);  // drain the very last tile
-        flush_span(span1 - 1);
+        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 4));  // drain the last tile
+        flush_bin(span1 - 1, BPS - 1);
     }
+    if (ITEMS) return;
 
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
 #pragma unroll
@@ -454,7 +488,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 
     int ncand = 0, nres = 0;  // wave-uniform
     int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
-    int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap;
+    int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     if (!force_fb) {
@@ -511,7 +545,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
-                        if (pos < a.rescan_cap) rr[pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                        if (pos < a.rescan_cap) {
+                            rr[2 * pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                            rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
+                        }
                     }
                     ncand += __popcll(cm);
                     nres += __popcll(rm);
@@ -572,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1];
     if (qvalid && !force_fb) {
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
-        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap;
+        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
         // second minimum and span of every ACTIVE superbin, loaded up front so the latencies overlap
         float sm2v[V];
         int spanv[V];
@@ -605,7 +642,10 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                     if (!(bm1 <= that)) continue;
                     if (a.bin_m2[o] <= that) {
                         const int pos = atomicAdd(cnt_r, 1);
-                        if (pos < a.rescan_cap) rr[pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                        if (pos < a.rescan_cap) {
+                            rr[2 * pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                            rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
+                        }
                     } else {
                         const int pos = atomicAdd(cnt_c, 1);
                         if (pos < a.cand_cap)

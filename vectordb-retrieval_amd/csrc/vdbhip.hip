@@ -13,6 +13,7 @@
 #include "refine.hpp"
 #include "scan.hpp"
 #include "ivf.hpp"
+#include "ivf_mfma.hpp"
 
 using namespace vdb;
 
@@ -92,6 +93,13 @@ struct vdb_index_s {
     std::vector<int64_t> ivf_offsets_host;   // [nlist+1]
     std::vector<int32_t> ivf_list_of_row;    // [N] list of every indexed row (original order)
     DevBuf ivf_offsets, ivf_ids, ivf_probe_d, ivf_probe_i;
+    // list-major MFMA scan (D <= 128): panel space = lists padded to whole 512-row spans
+    bool ivf_mfma_ok = false, ivf_last_mfma = false;
+    int64_t ivf_pspans = 0;
+    int ivf_max_pspans = 0;
+    DevBuf ivf_list_pspan0, ivf_span_row0, ivf_span_valid;
+    DevBuf ivf_cnt, ivf_cursor, ivf_slot_off, ivf_list_item0, ivf_item_list, ivf_item_slot0, ivf_item_bin0, ivf_plan,
+        ivf_slot_query, ivf_slot_of;
 };
 
 namespace {
@@ -140,6 +148,31 @@ void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
 }
 
 // ---- index build ---------------------------------------------------------------------------------
+// exact row norms + corpus statistics of h->x32 (N rows) -> scales of the fp16 scan copy
+void index_stats(vdb_index_s *h, hipStream_t st) {
+    const int64_t n = h->N;
+    h->xnorm2.reserve((size_t)n * sizeof(float));
+    h->stats.reserve(sizeof(IndexStats));
+    VDB_HIP(hipMemsetAsync(h->stats.p, 0, sizeof(IndexStats), st));
+    corpus_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, h->D4,
+                                                                                h->xnorm2.as<float>(),
+                                                                                h->stats.as<IndexStats>());
+    VDB_HIP(hipGetLastError());
+    IndexStats hs;
+    VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipStreamSynchronize(st));
+    memcpy(&h->absmax, &hs.absmax_bits, 4);
+    memcpy(&h->maxnorm2, &hs.maxnorm2_bits, 4);
+    h->nonfinite = hs.nonfinite != 0;
+    h->corpus_int_unscaled = !hs.not_integer && !h->nonfinite && h->absmax <= 2048.f;
+    h->sx = 1.f;
+    if (!h->corpus_int_unscaled && h->absmax > 0.f && !h->nonfinite) {
+        int e;
+        frexpf(h->absmax, &e);
+        h->sx = ldexpf(1.f, 14 - e);  // absmax*sx in [8192, 16384)
+    }
+}
+
 void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base,
                  hipStream_t st) {
     if (n < 0) throw Error(VDB_ERR_INVALID, "negative row count");
@@ -158,24 +191,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     if (D4 != D) VDB_HIP(hipMemsetAsync(h->x32.p, 0, (size_t)n * D4 * sizeof(float), st));
     VDB_HIP(hipMemcpy2DAsync(h->x32.p, (size_t)D4 * 4, x_dev_or_host, (size_t)D * 4, (size_t)D * 4, (size_t)n,
                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    h->xnorm2.reserve((size_t)n * sizeof(float));
-    h->stats.reserve(sizeof(IndexStats));
-    VDB_HIP(hipMemsetAsync(h->stats.p, 0, sizeof(IndexStats), st));
-    corpus_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D4, h->xnorm2.as<float>(), h->stats.as<IndexStats>());
-    VDB_HIP(hipGetLastError());
-    IndexStats hs;
-    VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-    VDB_HIP(hipStreamSynchronize(st));
-    memcpy(&h->absmax, &hs.absmax_bits, 4);
-    memcpy(&h->maxnorm2, &hs.maxnorm2_bits, 4);
-    h->nonfinite = hs.nonfinite != 0;
-    h->corpus_int_unscaled = !hs.not_integer && !h->nonfinite && h->absmax <= 2048.f;
-    h->sx = 1.f;
-    if (!h->corpus_int_unscaled && h->absmax > 0.f && !h->nonfinite) {
-        int e;
-        frexpf(h->absmax, &e);
-        h->sx = ldexpf(1.f, 14 - e);  // absmax*sx in [8192, 16384)
-    }
+    index_stats(h, st);
     const bool dims_ok = D <= 4096;
     if (dims_ok && !h->nonfinite) {
         const int64_t ntiles = h->Npad / kTileRows;
@@ -186,6 +202,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
         h->bias.reserve((size_t)h->Npad * sizeof(float));
         build_bias_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(h->xnorm2.as<float>(), n, h->Npad, h->metric, h->bias.as<float>());
         VDB_HIP(hipGetLastError());
+        IndexStats hs;
         VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
         VDB_HIP(hipStreamSynchronize(st));
         h->corpus_fp16_exact = hs.not_fp16_exact == 0;
@@ -374,7 +391,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     ws.sb_m2.reserve((size_t)nsb * Qpad * sizeof(float));
     ws.sb_span.reserve((size_t)nsb * Qpad * sizeof(int32_t));
     ws.cand.reserve((size_t)nq * cand_cap * sizeof(int32_t));
-    ws.rescan.reserve((size_t)nq * rescan_cap * sizeof(int32_t));
+    ws.rescan.reserve((size_t)nq * rescan_cap * 2 * sizeof(int32_t));
     ws.counts.reserve((size_t)nq * 2 * sizeof(int32_t));
     ws.fallback.reserve((size_t)nq * sizeof(int32_t));
     ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
@@ -613,7 +630,9 @@ int vdb_destroy(vdb_handle h) {
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
         DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->ivf_offsets, &h->ivf_ids,
-                         &h->ivf_probe_d, &h->ivf_probe_i};
+                         &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
+                         &h->ivf_cnt, &h->ivf_cursor, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
+                         &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_query, &h->ivf_slot_of};
         for (auto b : all) b->release();
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
@@ -726,7 +745,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.nprobe = h->nprobe;
         s.last_candidates = s.last_rescan_bins = s.last_fallback_queries = 0;
         s.last_scan_ms = s.last_total_ms = 0.f;
-        if (h->ws.small.p && h->last.last_path == VDB_PATH_MFMA_SCAN) {
+        if (h->ws.small.p && (h->last.last_path == VDB_PATH_MFMA_SCAN || (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma))) {
             unsigned char buf[64];
             VDB_HIP(hipDeviceSynchronize());
             VDB_HIP(hipMemcpy(buf, h->ws.small.p, 64, hipMemcpyDeviceToHost));
@@ -734,6 +753,11 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
             unsigned long long c[2];
             memcpy(&fb, buf, 4);
             memcpy(c, buf + 16, 16);
+            if (h->last.last_path == VDB_PATH_IVF) {
+                unsigned long long f2;
+                memcpy(&f2, buf + 32, 8);
+                fb = (int32_t)f2;
+            }
             s.last_fallback_queries = fb;
             s.last_candidates = (int64_t)c[0];
             s.last_rescan_bins = (int64_t)c[1];
