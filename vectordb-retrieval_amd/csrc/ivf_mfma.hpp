@@ -16,8 +16,8 @@
 
 namespace vdb {
 
-constexpr int kIvfBT = 4;                      // tiles per level-1 bin: 64-row bins
-constexpr int kIvfBPS = kTilesPerSpan / kIvfBT;
+// tiles per level-1 bin: 4 (64-row bins) when few lists are probed, so that a query still owns several
+// times k bins; 16 (256-row bins, 4x fewer entries for the select) when nprobe is large.
 
 // ---- build: panels + bias over the list-padded panel space ------------------------------------------
 __global__ __launch_bounds__(256) void ivf_build_panels_kernel(const float *__restrict__ X, int D, int D4, int ksteps,
@@ -82,40 +82,77 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restric
     if (l >= 0 && l < nlist) atomicAdd(&cnt[l], 1);
 }
 
-// one thread: slot ranges (padded to `group`), work items (list x group of slots), output bin blocks
-__global__ void ivf_plan_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ list_pspan0, int nlist,
-                                int group, int max_items, int max_slots, int max_bins, int32_t *__restrict__ slot_off,
-                                int32_t *__restrict__ list_item0, int32_t *__restrict__ item_list,
-                                int32_t *__restrict__ item_slot0, int32_t *__restrict__ item_bin0, IvfPlan *plan) {
-    int slots = 0, items = 0, bins = 0, overflow = 0;
-    for (int l = 0; l < nlist; ++l) {
-        slot_off[l] = slots;
-        list_item0[l] = items;
-        const int c = cnt[l];
-        const int spans = list_pspan0[l + 1] - list_pspan0[l];
-        if (c > 0 && spans > 0) {
-            const int g = (c + group - 1) / group;
-            for (int j = 0; j < g; ++j) {
-                if (items < max_items) {
-                    item_list[items] = l;
-                    item_slot0[items] = slots + j * group;
-                    item_bin0[items] = bins;
-                } else {
-                    overflow = 1;
-                }
-                ++items;
-                bins += spans * 2 * kIvfBPS;
-            }
-            slots += g * group;
-        }
+// one workgroup: slot ranges (padded to `group`), work items (list x group of slots), output bin blocks.
+// Lists are handled 1024 at a time with a block-wide exclusive scan of (groups, bins).
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ list_pspan0, int nlist, int group,
+                                                        int bps, int max_items, int max_slots, int max_bins,
+                                                        int32_t *__restrict__ slot_off, int32_t *__restrict__ list_item0,
+                                                        int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
+                                                        int32_t *__restrict__ item_bin0, IvfPlan *plan) {
+    __shared__ int s_g[1024], s_b[1024];
+    __shared__ int s_items, s_bins, s_overflow;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_items = 0;
+        s_bins = 0;
+        s_overflow = 0;
     }
-    slot_off[nlist] = slots;
-    list_item0[nlist] = items;
-    if (slots > max_slots || bins > max_bins || items > max_items) overflow = 1;
-    plan->n_items = overflow ? 0 : items;
-    plan->n_slots = slots;
-    plan->n_bins = bins;
-    plan->overflow = overflow;
+    __syncthreads();
+    for (int l0 = 0; l0 < nlist; l0 += 1024) {
+        const int l = l0 + tid;
+        int g = 0, bins_per_item = 0;
+        if (l < nlist) {
+            const int c = cnt[l];
+            const int spans = list_pspan0[l + 1] - list_pspan0[l];
+            if (c > 0 && spans > 0) {
+                g = (c + group - 1) / group;
+                bins_per_item = spans * 2 * bps;
+            }
+        }
+        s_g[tid] = g;
+        s_b[tid] = g * bins_per_item;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan of both arrays
+            const int vg = tid >= o ? s_g[tid - o] : 0;
+            const int vb = tid >= o ? s_b[tid - o] : 0;
+            __syncthreads();
+            s_g[tid] += vg;
+            s_b[tid] += vb;
+            __syncthreads();
+        }
+        const int item0 = s_items + s_g[tid] - g;               // exclusive prefixes
+        const int bin0 = s_bins + s_b[tid] - g * bins_per_item;
+        if (l < nlist) {
+            slot_off[l] = item0 * group;                         // every item owns `group` slots
+            list_item0[l] = item0;
+            for (int j = 0; j < g; ++j) {
+                if (item0 + j < max_items) {
+                    item_list[item0 + j] = l;
+                    item_slot0[item0 + j] = (item0 + j) * group;
+                    item_bin0[item0 + j] = bin0 + j * bins_per_item;
+                } else {
+                    s_overflow = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            s_items += s_g[1023];
+            s_bins += s_b[1023];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int items = s_items, bins = s_bins, slots = items * group;
+        slot_off[nlist] = slots;
+        list_item0[nlist] = items;
+        const int overflow = (s_overflow || slots > max_slots || bins > max_bins || items > max_items) ? 1 : 0;
+        plan->n_items = overflow ? 0 : items;
+        plan->n_slots = slots;
+        plan->n_bins = bins;
+        plan->overflow = overflow;
+    }
 }
 
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
@@ -171,6 +208,7 @@ struct IvfSelectArgs {
     const int32_t *slot_off, *list_item0, *item_bin0, *list_pspan0, *span_row0, *span_valid;
     int64_t nq;
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
+    int bt, bps;                  // tiles per bin, bins per (span, lane half)
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
 };
@@ -193,7 +231,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
             if (l < 0 || slot < 0) continue;
             const int rel = slot - a.slot_off[l];
             const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
-            const int nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * kIvfBPS;
+            const int nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * a.bps;
             if (E + nb > a.max_entries || nb > 65535) {
                 fb = true;
                 break;
@@ -235,10 +273,10 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     const int rel = a.slot_of[(size_t)q * a.nprobe + p] - a.slot_off[l];
                     const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
                     const float m2 = a.bin_m2[((size_t)a.item_bin0[item] + ei) * a.group + col];
-                    const int span_local = ei / (2 * kIvfBPS), hh = (ei / kIvfBPS) & 1, bt = ei % kIvfBPS;
+                    const int span_local = ei / (2 * a.bps), hh = (ei / a.bps) & 1, bt = ei % a.bps;
                     const int pspan = a.list_pspan0[l] + span_local;
-                    row0 = a.span_row0[pspan] + hh * kBinRows + bt * (kIvfBT * 16);
-                    row1 = row0 + kIvfBT * 16;
+                    row0 = a.span_row0[pspan] + hh * kBinRows + bt * (a.bt * 16);
+                    row1 = row0 + a.bt * 16;
                     const int end = a.span_row0[pspan] + a.span_valid[pspan];
                     if (row1 > end) row1 = end;
                     resc = m2 <= that;
