@@ -63,3 +63,21 @@ def test_harness_swallows_valueerror_like_the_reference():
     gt = np.stack([np.argsort(np.linalg.norm(X - q, axis=1))[:3] for q in Q])
     out = harness.run_single_algorithm(Flaky("f", 3), X, Q, gt, 3)
     assert out["metrics"]["used_batch_api"] is False and out["metrics"]["recall@1"] == 1.0
+
+
+def test_ground_truth_through_the_kernel(oracle, tmp_path):
+    """dataset.py:497-504: GT = argsort(norm(train - q))[:k], int32 -- here via the HIP path, k = 100/200;
+    the corpus is uploaded straight from a read-only .npy memory map (dataset.py:397, 414)."""
+    from vdbhip import harness, io
+    from oracle import ref_semantics as rs
+
+    X, Q = rs.random_dataset(32, 50000, 300, 11)
+    np.save(tmp_path / "train.npy", X)
+    mm = io.open_npy_rows(tmp_path / "train.npy")
+    assert not mm.flags.writeable
+    gt = harness.ground_truth(mm, Q, k=200, metric="l2")
+    assert gt.dtype == np.int32 and gt.shape == (300, 200)
+    np.testing.assert_array_equal(gt, oracle.knn(X, Q, 200, "l2")[1].astype(np.int32))
+    np.testing.assert_array_equal(gt[:20, :100], rs.ground_truth_l2(X, Q[:20], 100))
+    gtc = harness.ground_truth(X, Q, k=100, metric="ip", normalize=True)
+    np.testing.assert_array_equal(gtc, oracle.knn(rs.safe_normalize(X), rs.safe_normalize(Q), 100, "ip")[1].astype(np.int32))

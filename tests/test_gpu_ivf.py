@@ -185,3 +185,40 @@ def test_plugin_conventions(vdb, oracle):
     do, io = oracle.knn(X, Q, 5, "l2")
     np.testing.assert_array_equal(i, io)
     np.testing.assert_array_equal(d, do)
+
+
+def test_ivf_persistence_round_trip(vdb, tmp_path):
+    """save_index / load_index hook (base_algorithm.py:98-120) with the reference's artifact protocol:
+    manifest + WRITE_COMPLETE sentinel, refusal of incomplete or mismatching artifacts
+    (idiom of the reference's tests/algorithms/test_covertree_v2_2.py persistence tests)."""
+    X, Q = _data(6000, 16, 25, 8)
+    a = vdb.get_algorithm_instance("HipApproximateSearch", 16, name="ivf", index_type="IVF16,Flat", metric="l2",
+                                   nprobe=4, niter=5)
+    with pytest.raises(RuntimeError):
+        a.save_index(str(tmp_path / "art"))
+    a.build_index(X)
+    d0, i0 = a.batch_search(Q, k=5)
+    info = a.save_index(str(tmp_path / "art"), context={"build_metrics": {"build_time_s": 1.5}, "config_hash": "abc"})
+    assert (tmp_path / "art" / "WRITE_COMPLETE").is_file() and info["build_time_s"] == 1.5
+    with pytest.raises(FileExistsError):
+        a.save_index(str(tmp_path / "art"))
+    a.save_index(str(tmp_path / "art"), context={"force_rebuild": True, "config_hash": "abc"})
+    b = vdb.get_algorithm_instance("HipApproximateSearch", 16, name="ivf2", index_type="IVF16,Flat", metric="l2",
+                                   nprobe=4)
+    b.load_index(str(tmp_path / "art"), context={"config_hash": "abc"})
+    d1, i1 = b.batch_search(Q, k=5)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    with pytest.raises(ValueError):
+        b.load_index(str(tmp_path / "art"), context={"config_hash": "zzz"})
+    c = vdb.get_algorithm_instance("HipApproximateSearch", 16, name="ivf3", index_type="IVF32,Flat", metric="l2")
+    with pytest.raises(ValueError):
+        c.load_index(str(tmp_path / "art"))
+    (tmp_path / "art" / "WRITE_COMPLETE").unlink()
+    with pytest.raises(FileNotFoundError):
+        b.load_index(str(tmp_path / "art"))
+    with pytest.raises(FileNotFoundError):
+        b.load_index(str(tmp_path / "missing"))
+    # algorithms without persistence keep the base-class behaviour
+    with pytest.raises(NotImplementedError):
+        vdb.HipExactSearch("e", 4).save_index(str(tmp_path / "x"))

@@ -143,3 +143,27 @@ def test_synthetic_datasets_match_reference_recipe(golden_dir):
     assert 400 < np.linalg.norm(xs, axis=1).mean() < 560
     xs2, _ = datasets.sift_like(2000, 50, 128, 1234)
     np.testing.assert_array_equal(xs, xs2)
+
+
+def test_fvecs_ivecs_readers(tmp_path):
+    """Correct TEXMEX readers (the reference's _read_fvecs value-casts the int32 payload, dataset.py:534-545)."""
+    from vdbhip import io
+
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 12)).astype(np.float32)
+    x[0, 0] = 1.0
+    gt = rng.integers(0, 1000, size=(5, 7)).astype(np.int32)
+    io.write_fvecs(tmp_path / "b.fvecs", x)
+    io.write_ivecs(tmp_path / "g.ivecs", gt)
+    back = io.read_fvecs(tmp_path / "b.fvecs")
+    np.testing.assert_array_equal(back, x)
+    assert back[0, 0] == 1.0                      # not 1.0653532e9
+    np.testing.assert_array_equal(io.read_fvecs(tmp_path / "b.fvecs", limit=10), x[:10])
+    np.testing.assert_array_equal(io.read_ivecs(tmp_path / "g.ivecs"), gt)
+    (tmp_path / "bad.fvecs").write_bytes(np.array([3, 1, 2], np.int32).tobytes())
+    with pytest.raises(ValueError):
+        io.read_fvecs(tmp_path / "bad.fvecs")
+    np.save(tmp_path / "c.npy", x)
+    m = io.open_npy_rows(tmp_path / "c.npy", limit=20)
+    assert isinstance(m, np.memmap) or isinstance(m.base, np.memmap)
+    np.testing.assert_array_equal(np.asarray(m), x[:20])

@@ -171,6 +171,23 @@ def run_benchmark(config: Dict[str, Any]) -> Dict[str, Dict[str, Any]]:
     return results
 
 
+def ground_truth(train: np.ndarray, test: np.ndarray, k: int = 100, metric: str = "l2",
+                 normalize: bool = False, device: int = 0) -> np.ndarray:
+    """Brute-force ground truth through the HIP kernels: what the reference computes with
+    per-query `argsort(norm(train - q))[:k]` (dataset.py:497-504, 657-663; int32 output) or with FAISS
+    `IndexFlatIP/L2` for MS MARCO (dataset.py:858-964; `normalize=True` = normalize_cosine_groundtruth)."""
+    from .algorithms import HipExactSearch, _safe_normalize
+
+    x = np.ascontiguousarray(train, np.float32)
+    q = np.ascontiguousarray(test, np.float32)
+    if normalize:
+        x, q = _safe_normalize(x), _safe_normalize(q)
+    algo = HipExactSearch("ground_truth", x.shape[1], metric="l2" if metric == "l2" else "ip", device=device)
+    algo.build_index(x)
+    _, idx = algo.batch_search(q, k=k)
+    return idx.astype(np.int32)
+
+
 def load_config(path: str) -> Dict[str, Any]:
     import yaml
 

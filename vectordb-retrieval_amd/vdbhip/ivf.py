@@ -161,6 +161,86 @@ class HipApproximateSearch(BaseAlgorithm):
     def get_memory_usage(self) -> float:
         return self.index.stats()["bytes_resident"] / (1024.0 * 1024.0) if self.index else 0.0
 
+    # ---- persistence through the BaseAlgorithm hook (base_algorithm.py:98-120) ---------------------------
+    # Layout and protocol follow the reference's only implementation (covertree_v2_2.py:101-182, 184-282):
+    # temp dir + manifest.json + WRITE_COMPLETE sentinel written last + atomic rename; load refuses an
+    # incomplete artifact or a manifest that does not match this instance.
+    _FORMAT = "vdbhip-ivfflat-v1"
+
+    def save_index(self, artifact_dir: str, context=None):
+        import json
+        import shutil
+        import tempfile
+        from pathlib import Path
+
+        if not self.index_built or self.index is None:
+            raise RuntimeError("Cannot persist HipApproximateSearch before build_index has completed.")
+        context = context or {}
+        target = Path(artifact_dir)
+        target.parent.mkdir(parents=True, exist_ok=True)
+        if target.exists():
+            if not bool(context.get("force_rebuild", False)):
+                raise FileExistsError(f"Artifact directory already exists: {target}. "
+                                      "Set persistence.force_rebuild=true to overwrite.")
+            shutil.rmtree(target)
+        tmp = Path(tempfile.mkdtemp(prefix=f".{target.name}.tmp.", dir=str(target.parent)))
+        try:
+            np.save(tmp / "vectors.npy", self.vectors, allow_pickle=False)
+            np.save(tmp / "centroids.npy", self.index.centroids(), allow_pickle=False)
+            np.save(tmp / "list_of_row.npy", self.index.assignment(), allow_pickle=False)
+            build_metrics = dict(context.get("build_metrics", {}))
+            manifest = {"format": self._FORMAT, "algorithm": type(self).__name__, "dimension": self.dimension,
+                        "index_type": self.index_type, "metric": self.metric, "nlist": self.index.nlist,
+                        "nprobe": self.index.nprobe, "n_vectors": int(self.index.ntotal),
+                        "config_hash": context.get("config_hash"),
+                        "files": {"vectors": "vectors.npy", "centroids": "centroids.npy",
+                                  "list_of_row": "list_of_row.npy"}}
+            (tmp / "manifest.json").write_text(json.dumps(manifest, indent=2), encoding="utf-8")
+            (tmp / "build_metrics.json").write_text(json.dumps(build_metrics, indent=2), encoding="utf-8")
+            (tmp / "WRITE_COMPLETE").write_text("ok\n", encoding="utf-8")
+            tmp.rename(target)
+        except Exception:
+            shutil.rmtree(tmp, ignore_errors=True)
+            raise
+        return {"artifact_dir": str(target), "manifest_path": str(target / "manifest.json"),
+                "build_time_s": float(build_metrics.get("build_time_s", 0.0) or 0.0)}
+
+    def load_index(self, artifact_dir: str, context=None):
+        import json
+        from pathlib import Path
+
+        path = Path(artifact_dir)
+        if not path.is_dir():
+            raise FileNotFoundError(f"Persisted HipApproximateSearch artifact directory not found: {path}")
+        if not (path / "WRITE_COMPLETE").is_file():
+            raise FileNotFoundError(f"Artifact is incomplete or corrupted (missing WRITE_COMPLETE): {path}")
+        manifest = json.loads((path / "manifest.json").read_text(encoding="utf-8"))
+        for key, want in (("format", self._FORMAT), ("dimension", self.dimension), ("index_type", self.index_type),
+                          ("metric", self.metric)):
+            if manifest.get(key) != want:
+                raise ValueError(f"Persisted index mismatch for '{key}': artifact has {manifest.get(key)!r}, "
+                                 f"this instance expects {want!r}")
+        expected_hash = (context or {}).get("config_hash")
+        if expected_hash and manifest.get("config_hash") and manifest["config_hash"] != expected_hash:
+            raise ValueError("Persisted index was built with a different configuration (config_hash mismatch)")
+        vectors = np.load(path / manifest["files"]["vectors"], mmap_mode="r")
+        centroids = np.load(path / manifest["files"]["centroids"])
+        self.vectors = vectors
+        self.index = IVFFlatIndex(self.dimension, int(manifest["nlist"]), self.metric, self.device)
+        self.index.set_centroids(centroids)       # no k-means: the stored quantizer is reused
+        self.index.add(vectors)                   # deterministic: reproduces the stored lists exactly
+        stored = np.load(path / manifest["files"]["list_of_row"])
+        if not np.array_equal(stored, self.index.assignment()):
+            raise ValueError("Persisted inverted lists do not match the re-assigned corpus")
+        self.index.set_nprobe(int(self.config.get("nprobe", manifest.get("nprobe", 1))))
+        self.index_built = True
+        metrics = {}
+        bm = path / "build_metrics.json"
+        if bm.is_file():
+            metrics = json.loads(bm.read_text(encoding="utf-8"))
+        return {"artifact_dir": str(path), "manifest_path": str(path / "manifest.json"),
+                "build_time_s": float(metrics.get("build_time_s", 0.0) or 0.0)}
+
 
 class HipIVFIndexer(BaseIndexer):
     """FaissFactoryIndexer / FaissIVFIndexer semantics for IVF-Flat keys."""
