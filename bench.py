@@ -134,19 +134,24 @@ def main() -> None:
     q_t = torch.from_numpy(Q).to(dev)
     D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    if world > 1:
+    sharded = world > 1 or os.environ.get("VDBHIP_BENCH_FORCE_SHARDED") == "1"   # (rehearsal of the N>1 code path)
+    if sharded:
         my_keys = torch.empty((nq, k), dtype=torch.float64, device=dev)
         my_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
         all_keys = torch.empty((world, nq, k), dtype=torch.float64, device=dev)
         all_ids = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
 
     def step():
-        if world == 1:
+        if not sharded:
             index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
         else:
             index.search_partial_device(q_t.data_ptr(), nq, k, my_keys.data_ptr(), my_ids.data_ptr(), stream)
-            dist.all_gather_into_tensor(all_keys, my_keys)
-            dist.all_gather_into_tensor(all_ids, my_ids)
+            if world > 1:
+                dist.all_gather_into_tensor(all_keys, my_keys)
+                dist.all_gather_into_tensor(all_ids, my_ids)
+            else:
+                all_keys.copy_(my_keys.unsqueeze(0))
+                all_ids.copy_(my_ids.unsqueeze(0))
             vdbhip.merge_partials_device(metric, local_rank, all_keys.data_ptr(), all_ids.data_ptr(), world, nq, k,
                                          D_t.data_ptr(), I_t.data_ptr(), stream)
 

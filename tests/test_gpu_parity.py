@@ -313,3 +313,35 @@ def test_sharded_partials_merge_is_shard_count_invariant(vdb, oracle):
             np.testing.assert_array_equal(D.cpu().numpy(), Do)
             for s in shards:
                 s.close()
+
+
+def test_many_queries_multi_batch_and_large_k(vdb, oracle):
+    """nq above the library's internal 16384-query batch; k = 1000 (8 list slots per lane in the refine kernel)."""
+    X, Q = _make(40000, 32, 40000, "gauss", 17)
+    idx = vdb.FlatIndex(32, "l2", 0)
+    idx.add(X)
+    D, I = idx.search(Q, 3)
+    sample = np.random.default_rng(0).choice(len(Q), 300, replace=False)
+    Do, Io = oracle.knn(X, Q[sample], 3, "l2")
+    np.testing.assert_array_equal(I[sample], Io)
+    np.testing.assert_array_equal(D[sample], Do)
+    D, I = idx.search(Q[:20], 1000)
+    Do, Io = oracle.knn(X, Q[:20], 1000, "l2")
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    with pytest.raises(RuntimeError):
+        idx.search(Q[:2], 4096)          # k above the supported 2048
+    idx.close()
+
+
+def test_sharded_algorithm_single_rank(vdb, oracle):
+    """HipShardedExactSearch without an initialised process group behaves like one shard (world = 1)."""
+    pytest.importorskip("torch")
+    X, Q = _make(50000, 48, 100, "gauss", 4)
+    a = vdb.get_algorithm_instance("HipShardedExactSearch", 48, name="sh", metric="ip", device=0)
+    a.build_index(X)
+    d, i = a.batch_search(Q, k=10)
+    do, io = oracle.knn(X, Q, 10, "ip")
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(d, do)
+    assert a.shard == (0, 50000)

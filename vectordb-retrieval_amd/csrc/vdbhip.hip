@@ -77,7 +77,7 @@ struct vdb_index_s {
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
     // options
-    int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0;
+    int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0;
     // per-search
     Workspace ws;
     vdb_stats_t last{};
@@ -226,7 +226,7 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     int64_t spc_hi = g.nspans / (2 * (int64_t)k);           // nsb >= 4k
     int64_t spc_lo = (g.nspans + 511) / 512;                // nsb <= 1024
     if (spc_hi < 1 || spc_hi < spc_lo) return g;
-    int64_t spc = std::min<int64_t>(16, spc_hi);
+    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : 16, spc_hi);
     spc = std::max<int64_t>(spc, spc_lo);
     if (spc < 2 && g.nspans >= 64) spc = std::min<int64_t>(2, spc_hi);
     g.spc = (int)spc;
@@ -793,6 +793,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "scan_variant") {
             if (value < 0 || value >= kNumScanVariants) throw Error(VDB_ERR_INVALID, "scan_variant out of range");
             h->scan_variant = (int)value;
+        } else if (k == "spans_per_chunk") {  // tuning: rows per workgroup chunk = 512 * value (0 = default 16)
+            if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "spans_per_chunk out of range");
+            h->spc_override = (int)value;
         } else if (k == "select_variant") {
             h->select_variant = value != 0;
         } else if (k == "list_cap") {
