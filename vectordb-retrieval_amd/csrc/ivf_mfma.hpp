@@ -74,12 +74,33 @@ struct IvfPlan {          // device-resident scalars written by ivf_plan_kernel
     int32_t overflow;     // plan did not fit the buffers: the batch takes the exact list scan
 };
 
+// per-list probe counts.  Workgroup-local LDS histogram first (nlist <= kIvfLdsLists), then one global atomic
+// per (workgroup, touched list): 1.28 M probes on 1024 lists would otherwise serialise on 1024 addresses.
+constexpr int kIvfLdsLists = 8192;
+constexpr int kIvfPairsPerBlock = 4096;
+
 __global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restrict__ probes, int64_t n, int nlist,
                                                         int32_t *__restrict__ cnt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t l = probes[i];
-    if (l >= 0 && l < nlist) atomicAdd(&cnt[l], 1);
+    extern __shared__ int ivf_hist[];
+    const bool use_lds = nlist <= kIvfLdsLists;
+    if (use_lds) {
+        for (int l = threadIdx.x; l < nlist; l += 256) ivf_hist[l] = 0;
+        __syncthreads();
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * kIvfPairsPerBlock;
+    for (int j = threadIdx.x; j < kIvfPairsPerBlock; j += 256) {
+        const int64_t i = i0 + j;
+        if (i >= n) break;
+        const int64_t l = probes[i];
+        if (l >= 0 && l < nlist) atomicAdd(use_lds ? &ivf_hist[l] : &cnt[l], 1);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int l = threadIdx.x; l < nlist; l += 256) {
+            const int c = ivf_hist[l];
+            if (c) atomicAdd(&cnt[l], c);
+        }
+    }
 }
 
 // one workgroup: slot ranges (padded to `group`), work items (list x group of slots), output bin blocks.
@@ -155,46 +176,66 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
     }
 }
 
+// slot of every (query, probe): workgroup-local rank from an LDS histogram + one global cursor bump per
+// (workgroup, touched list).  Slot order inside a list is arbitrary (results do not depend on it).
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
                                                           int nlist, const int32_t *__restrict__ slot_off,
                                                           const int32_t *__restrict__ list_pspan0,
                                                           int32_t *__restrict__ cursor, const IvfPlan *plan,
                                                           int32_t *__restrict__ slot_query, int32_t *__restrict__ slot_of) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * nprobe) return;
-    const int64_t l = probes[i];
-    int slot = -1;
-    // (an empty list owns no slots: probing it contributes nothing)
-    if (!plan->overflow && l >= 0 && l < nlist && list_pspan0[l + 1] > list_pspan0[l]) {
-        slot = slot_off[l] + atomicAdd(&cursor[l], 1);
-        slot_query[slot] = (int32_t)(i / nprobe);
+    extern __shared__ int ivf_hist[];   // [nlist] local counts, then global bases
+    const bool use_lds = nlist <= kIvfLdsLists;
+    const int64_t n = nq * nprobe;
+    const int64_t i0 = (int64_t)blockIdx.x * kIvfPairsPerBlock;
+    const bool dead = plan->overflow != 0;
+    if (use_lds) {
+        for (int l = threadIdx.x; l < nlist; l += 256) ivf_hist[l] = 0;
+        __syncthreads();
     }
-    slot_of[i] = slot;
+    constexpr int PER = kIvfPairsPerBlock / 256;
+    int rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = i0 + threadIdx.x + u * 256;
+        rank[u] = -1;
+        if (i < n && !dead) {
+            const int64_t l = probes[i];
+            // (an empty list owns no slots: probing it contributes nothing)
+            if (l >= 0 && l < nlist && list_pspan0[l + 1] > list_pspan0[l])
+                rank[u] = use_lds ? atomicAdd(&ivf_hist[l], 1) : atomicAdd(&cursor[l], 1);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int l = threadIdx.x; l < nlist; l += 256) {
+            const int c = ivf_hist[l];
+            ivf_hist[l] = c ? atomicAdd(&cursor[l], c) : 0;   // -> global base of this workgroup's run
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = i0 + threadIdx.x + u * 256;
+        if (i >= n) continue;
+        int slot = -1;
+        if (rank[u] >= 0) {
+            const int64_t l = probes[i];
+            slot = slot_off[l] + rank[u] + (use_lds ? ivf_hist[l] : 0);
+            slot_query[slot] = (int32_t)(i / nprobe);
+        }
+        slot_of[i] = slot;
+    }
 }
 
-// fp16 B-fragment panels of the gathered query slots (slot_query = -1 -> zero column)
-__global__ __launch_bounds__(256) void ivf_qpanels_kernel(const float *__restrict__ Q, int D, int ksteps,
-                                                          const int32_t *__restrict__ slot_query, const IvfPlan *plan,
-                                                          const QueryBatchInfo *__restrict__ info,
-                                                          half8 *__restrict__ qpanels) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = (int)(gid & 63);
-    const int64_t tk = gid >> 6;
-    const int ks = (int)(tk % ksteps);
-    const int64_t tile = tk / ksteps;
-    if (tile * 32 >= plan->n_slots) return;
-    const float bs = info->bscale;
-    const int q = slot_query[tile * 32 + (lane & 31)];
-    const int d0 = ks * 16 + (lane >> 5) * 8;
-    half8 out;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int d = d0 + j;
-        float v = 0.f;
-        if (q >= 0 && d < D) v = Q[(size_t)q * D + d] * bs;
-        out[j] = (_Float16)v;
-    }
-    qpanels[gid] = out;
+// scaled fp16 copy of the query rows, [nq][16*ksteps]; the scan kernel gathers its B fragments from it
+__global__ __launch_bounds__(256) void ivf_qrows_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
+                                                        const QueryBatchInfo *__restrict__ info,
+                                                        _Float16 *__restrict__ qrows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * Dpad) return;
+    const int64_t q = i / Dpad;
+    const int d = (int)(i - q * Dpad);
+    qrows[i] = (_Float16)(d < D ? Q[(size_t)q * D + d] * info->bscale : 0.f);
 }
 
 // ---- select over the bins of a query's probed lists ----------------------------------------------------
@@ -213,40 +254,75 @@ struct IvfSelectArgs {
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
 };
 
-// one wave per query; the bin minima of the query live in LDS (max_entries floats + descriptors per wave)
-__global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 2 waves: 64 KiB of LDS
+// one wave per query.  Phase 1: lane p resolves probe p (list, item, slot column, #bins) -- the dependent
+// index loads of all probes overlap instead of chaining; a wave prefix sum lays the probes' bins out as one
+// flat entry range.  Phase 2: lanes stride over the flat entries (binary search probe-of-entry in LDS) and
+// copy the bin minima into LDS with independent, per-probe-contiguous loads.  Phase 3: bitwise bisection for
+// the k-th smallest.  Phase 4: entries <= That become candidate rows or bins to re-scan.
+constexpr int kIvfMaxProbes = 512;
+
+__global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 2 waves per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char ivf_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 2 + wave));
     if (q >= a.nq) return;
-    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * a.max_entries * 2;
-    unsigned *desc = vals + a.max_entries;    // (probe << 16) | entry-in-item
+    // per wave: vals[max_entries] | p_off[kIvfMaxProbes+32] | p_base lo/hi [2*kIvfMaxProbes] | p_list[kIvfMaxProbes]
+    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.max_entries + 4 * kIvfMaxProbes + 64);
+    int *p_off = reinterpret_cast<int *>(vals + a.max_entries);
+    unsigned *p_base_lo = reinterpret_cast<unsigned *>(p_off + kIvfMaxProbes + 32);
+    unsigned *p_base_hi = p_base_lo + kIvfMaxProbes;
+    int *p_list = reinterpret_cast<int *>(p_base_hi + kIvfMaxProbes);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    bool fb = a.plan->overflow || a.info->force_fallback;
-    int E = 0;                                 // wave-uniform number of entries gathered
+    bool fb = a.plan->overflow || a.info->force_fallback || a.nprobe > kIvfMaxProbes;
+    int E = 0;
     if (!fb) {
-        for (int p = 0; p < a.nprobe; ++p) {
-            const int64_t l = a.probes[(size_t)q * a.nprobe + p];
-            const int slot = a.slot_of[(size_t)q * a.nprobe + p];
-            if (l < 0 || slot < 0) continue;
-            const int rel = slot - a.slot_off[l];
-            const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
-            const int nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * a.bps;
-            if (E + nb > a.max_entries || nb > 65535) {
-                fb = true;
-                break;
+        for (int p0 = 0; p0 < a.nprobe; p0 += 64) {
+            const int p = p0 + lane;
+            int nb = 0, lst = -1;
+            size_t base = 0;
+            if (p < a.nprobe) {
+                const int64_t l = a.probes[(size_t)q * a.nprobe + p];
+                const int slot = a.slot_of[(size_t)q * a.nprobe + p];
+                if (l >= 0 && slot >= 0) {
+                    const int rel = slot - a.slot_off[l];
+                    const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
+                    nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * a.bps;
+                    base = (size_t)a.item_bin0[item] * a.group + (size_t)col * nb;
+                    lst = (int)l;
+                }
             }
-            const float *src = a.bin_m1 + (size_t)a.item_bin0[item] * a.group + col;
-            for (int e = lane; e < nb; e += 64) {
-                vals[E + e] = sortable_u32(src[(size_t)e * a.group]);
-                desc[E + e] = ((unsigned)p << 16) | (unsigned)e;
+            int incl = nb;                                  // inclusive wave prefix sum of nb
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
             }
-            E += nb;
+            if (p < a.nprobe) {
+                p_off[p] = E + incl - nb;
+                p_base_lo[p] = (unsigned)base;
+                p_base_hi[p] = (unsigned)(base >> 32);
+                p_list[p] = lst;
+            }
+            E += __shfl(incl, 63);
         }
+        if (lane == 0) p_off[a.nprobe] = E;
+        if (E > a.max_entries) fb = true;
     }
     if (!fb && E < a.k) fb = true;            // not enough bins to bound the k-th neighbour: exact list scan
+    auto probe_of = [&](int e) {              // largest p with p_off[p] <= e  (p_off is non-decreasing)
+        int lo = 0, hi = a.nprobe;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (p_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
     int ncand = 0, nres = 0;
     if (!fb) {
+        for (int e = lane; e < E; e += 64) {
+            const int p = probe_of(e);
+            const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
+            vals[e] = sortable_u32(a.bin_m1[base + (e - p_off[p])]);
+        }
         unsigned ans = 0;
         for (int bit = 31; bit >= 0; --bit) {
             const unsigned trial = ans | ((1u << bit) - 1u);
@@ -259,20 +335,18 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         if (!(that < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
-        for (int base = 0; base < E && !fb; base += 64) {
-            const int e = base + lane;
+        for (int base_e = 0; base_e < E && !fb; base_e += 64) {
+            const int e = base_e + lane;
             bool cand = false, resc = false;
             int row0 = 0, row1 = 0;
             float m1 = 0.f;
             if (e < E) {
                 m1 = unsortable_f32(vals[e]);
                 if (m1 <= that) {
-                    const unsigned d = desc[e];
-                    const int p = (int)(d >> 16), ei = (int)(d & 0xFFFFu);
-                    const int64_t l = a.probes[(size_t)q * a.nprobe + p];
-                    const int rel = a.slot_of[(size_t)q * a.nprobe + p] - a.slot_off[l];
-                    const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
-                    const float m2 = a.bin_m2[((size_t)a.item_bin0[item] + ei) * a.group + col];
+                    const int p = probe_of(e), ei = e - p_off[p];
+                    const int l = p_list[p];
+                    const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
+                    const float m2 = a.bin_m2[base + ei];
                     const int span_local = ei / (2 * a.bps), hh = (ei / a.bps) & 1, bt = ei % a.bps;
                     const int pspan = a.list_pspan0[l] + span_local;
                     row0 = a.span_row0[pspan] + hh * kBinRows + bt * (a.bt * 16);

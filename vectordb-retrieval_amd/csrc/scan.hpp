@@ -43,6 +43,8 @@ struct ScanArgs {
     const int32_t *item_bin0;    // [items] first level-1 bin of the item's output block
     const int32_t *n_items;      // [1]
     const int32_t *list_pspan0;  // [nlist+1] panel spans of every list (lists are padded to whole spans)
+    const int32_t *slot_query;   // [slots] query of every slot (-1 = padding)
+    const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
 };
 
 // (score & ~0xFF) | id  -- one v_and_or_b32 when the mask lives in a VGPR (the id is wave-uniform)
@@ -161,13 +163,28 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
 
     // ---- B fragments: resident for the whole chunk ------------------------------------------------
     half8 b0[KSTEPS], b1[KSTEPS];
+    if (ITEMS) {  // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's query row
+        const int qa = a.slot_query[q0 + (lane & 31)], qb = a.slot_query[q0 + 32 + (lane & 31)];
+        const half8 *ra = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (16 * KSTEPS)) + h;
+        const half8 *rb = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qb < 0 ? 0 : qb) * (16 * KSTEPS)) + h;
+        half8 zero;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        b0[ks] = a.qpanels[((size_t)(q0 / 32 + 0) * KSTEPS + ks) * 64 + lane];
-        b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KSTEPS + ks) * 64 + lane];
+        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            b0[ks] = qa < 0 ? zero : ra[ks * 2];
+            b1[ks] = qb < 0 ? zero : rb[ks * 2];
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            b0[ks] = a.qpanels[((size_t)(q0 / 32 + 0) * KSTEPS + ks) * 64 + lane];
+            b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KSTEPS + ks) * 64 + lane];
+        }
     }
 
     const int nstages = (int)(span1 - span0) * SPS;
+    const int nb_item = (int)(span1 - span0) * 2 * BPS;    // ITEMS: bins per query slot in this item
 
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
@@ -216,13 +233,16 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     };
     // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
     auto flush_bin = [&](int64_t span, int bt) {
-        const size_t bin = ITEMS ? bin_base + (size_t)(((span - span0) * 2 + h) * BPS + bt)
-                                 : (size_t)((span * 2 + h) * BPS + bt);
-        const size_t o = bin * out_pitch + out_col;
+        // flat: [bin][query] (coalesced over the 32 queries of a lane half).  ITEMS: [item][slot][bin] so
+        // that the per-query select reads the bins of one probe as one contiguous run.
+        const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
+                                     (size_t)(((span - span0) * 2 + h) * BPS + bt)
+                               : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
+        const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            a.bin_m1[o + cb * 32] = m1[cb];
-            a.bin_m2[o + cb * 32] = m2[cb];
+            a.bin_m1[o + cb * cbs] = m1[cb];
+            a.bin_m2[o + cb * cbs] = m2[cb];
             if (!ITEMS) {
                 M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
                 if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
