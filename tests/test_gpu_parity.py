@@ -128,7 +128,10 @@ CASES = [
     (1, 8, 3, 1, "l2", "gauss"),
     (7, 3, 5, 4, "ip", "gauss"),
     (300, 50, 17, 10, "l2", "gauss"),
-    (5000, 128, 64, 10, "ip", "gauss"),
+    (5000, 128, 64, 10, "ip", "gauss"),     # dense small-corpus MFMA path (N <= 8192, nq >= 64)
+    (8000, 64, 200, 100, "l2", "gauss"),
+    (1024, 128, 500, 128, "l2", "sift"),     # IVF-coarse shape: top-128 of 1024 centroids
+    (700, 20, 64, 1, "ip", "glove"),
     (4097, 33, 9, 64, "l2", "gauss"),
     (3000, 200, 11, 5, "l2", "gauss"),      # small N: exhaustive exact kernel
     (2000, 768, 4, 10, "ip", "gauss"),
@@ -174,6 +177,8 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     if n >= 32768 and nq >= 64 and (n + 511) // 512 >= 2 * k:
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st
+    elif n <= 8192 and nq >= 64 and d <= 128 and 2 * k <= n:
+        assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, st   # dense path
     else:
         assert st["last_path_name"] == "exact_scan", st
     # the forced other path must give the same bits

@@ -1,0 +1,142 @@
+// dense.hpp -- small-corpus path (N <= 8192 rows: IVF coarse quantizers, k-means assignment, tiny indexes).
+//
+// With so few rows the bin-minimum select has nothing to work with (k is a sizeable fraction of N), so the
+// fp16 MFMA scores of ALL rows are written out (nq x Npad float32) and a per-query kernel keeps every row whose
+// score is within 2*eps of the k-th smallest one, re-scores those few rows in the canonical float64 arithmetic
+// and returns the exact top-k.  Same guarantee as the bin path with bins of one row: every true neighbour has
+// an approximate score <= tau + 2*eps.  Replaces a float64 pass over every (query, row) pair.
+#pragma once
+#include "common.hpp"
+#include "prep.hpp"
+#include "refine.hpp"
+#include "scan.hpp"
+
+namespace vdb {
+
+// one wave = one 32-row tile x 64 queries; 4 waves of a workgroup take 4 consecutive tiles
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void dense_scores_kernel(const half8 *__restrict__ panels, const float *__restrict__ bias,
+                                                           const half8 *__restrict__ qpanels,
+                                                           const QueryBatchInfo *__restrict__ info, int64_t ntiles,
+                                                           int64_t Npad, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int64_t qt = blockIdx.y;                          // 64-query tile
+    const float cs = info->cs;
+    const int64_t span = tile / kTilesPerSpan;
+    const int t = (int)(tile - span * kTilesPerSpan);
+    const int64_t row0 = span * kSpanRows + (int64_t)h * kBinRows + t * 16;
+    float16v acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 c = *reinterpret_cast<const float4 *>(bias + row0 + 4 * g);
+        acc0[4 * g + 0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
+        acc0[4 * g + 1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
+        acc0[4 * g + 2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
+        acc0[4 * g + 3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
+    }
+    acc1 = acc0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const half8 af = panels[((size_t)tile * KSTEPS + ks) * 64 + lane];
+        const half8 bf0 = qpanels[((size_t)(qt * 2 + 0) * KSTEPS + ks) * 64 + lane];
+        const half8 bf1 = qpanels[((size_t)(qt * 2 + 1) * KSTEPS + ks) * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf1, acc1, 0, 0, 0);
+    }
+    float4 *o0 = reinterpret_cast<float4 *>(out + (size_t)(qt * 64 + (lane & 31)) * Npad + row0);
+    float4 *o1 = reinterpret_cast<float4 *>(out + (size_t)(qt * 64 + 32 + (lane & 31)) * Npad + row0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o0[g] = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+        o1[g] = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+    }
+}
+
+struct DenseSelectArgs {
+    RefineCommon c;
+    const float *scores;       // [Qpad][Npad]
+    const float *eps;          // [nq]
+    const QueryBatchInfo *info;
+    int64_t nq, Npad;
+    int cand_cap;              // candidates kept in LDS per query
+    int32_t *fallback;         // [nq]
+    int32_t *fb_list;
+    int32_t *fb_count;
+    unsigned long long *stat_counters;
+    float *D;                  // final rows, or
+    int64_t *I;
+    double *pkeys;             // partial rows [nq][k]
+    int64_t *pids;
+};
+
+// one wave (= one workgroup) per query; LDS: Npad sortable scores + cand_cap row ids (<= ~40 KiB)
+template <int KPL>
+__global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x;
+    if (q >= a.nq) return;
+    unsigned *vals = reinterpret_cast<unsigned *>(dense_smem);
+    int *cands = reinterpret_cast<int *>(vals + a.Npad);
+    const int n = (int)a.Npad, k = a.c.k;
+    const float *src = a.scores + (size_t)q * a.Npad;
+    for (int i = lane * 4; i < n; i += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + i);
+        vals[i] = sortable_u32(v.x); vals[i + 1] = sortable_u32(v.y);
+        vals[i + 2] = sortable_u32(v.z); vals[i + 3] = sortable_u32(v.w);
+    }
+    unsigned ans = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = ans | ((1u << bit) - 1u);
+        int cnt = 0;
+        for (int i = lane; i < n; i += 64) cnt += (vals[i] <= trial) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (cnt < k) ans |= (1u << bit);
+    }
+    const float that = unsortable_f32(ans) + 2.0f * a.eps[q];
+    bool fb = a.info->force_fallback || !(that < 0.9e38f);
+    const unsigned tkey = sortable_u32(that);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int ncand = 0;
+    for (int base = 0; base < n && !fb; base += 64) {
+        const int i = base + lane;
+        const bool hit = i < n && vals[i] <= tkey;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int pos = ncand + __popcll(m & lt_mask);
+            if (pos < a.cand_cap) cands[pos] = i;
+        }
+        ncand += __popcll(m);
+    }
+    if (ncand > a.cand_cap) fb = true;
+    if (fb) {
+        if (lane == 0) {
+            a.fallback[q] = 1;
+            a.fb_list[atomicAdd(a.fb_count, 1)] = (int)q;
+        }
+        return;
+    }
+    const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+    WaveTopK<KPL> tk;
+    tk.init(k);
+    for (int base = 0; base < ncand; base += 64) {
+        const int i = base + lane;
+        bool valid = i < ncand;
+        const int64_t row = valid ? (int64_t)cands[i] : 0;
+        valid = valid && row < a.c.N;
+        uint64_t key = ~0ull;
+        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        tk.offer(key, a.c.id_base + row, valid);
+    }
+    const size_t o = (size_t)q * k;
+    write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
+                    a.pids ? a.pids + o : nullptr);
+    if (lane == 0) {
+        a.fallback[q] = 0;
+        atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
+    }
+}
+
+}  // namespace vdb

@@ -14,6 +14,7 @@
 #include "scan.hpp"
 #include "ivf.hpp"
 #include "ivf_mfma.hpp"
+#include "dense.hpp"
 
 using namespace vdb;
 
@@ -47,19 +48,21 @@ struct DevBuf {
 struct Workspace {
     DevBuf qpad, qpanels, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
+    DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
         const DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
                                &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
-                               &stage_i};
+                               &stage_i, &dense};
         size_t s = 0;
         for (auto b : all) s += b->cap;
         return s;
     }
     void release() {
         DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
-                         &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i};
+                         &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
+                         &dense};
         for (auto b : all) b->release();
     }
 };
@@ -328,6 +331,101 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 16);
 
     const long tslot = timing_begin(h, st);
+
+    // small corpora: dense fp16 scores + per-query guard + exact re-score of the few surviving rows
+    const bool use_dense = !use_scan && h->scan_ok && h->force_path != 1 && h->ksteps <= kMaxKSteps &&
+                           h->Npad <= 8192 && nq >= 64 && k <= 1024 && (int64_t)k * 2 <= h->N;
+    if (use_dense) {
+        const int64_t Qp = (nq + 63) / 64 * 64;
+        const int cand_cap = std::max(128, 2 * k + 64);
+        ws.info.reserve(sizeof(QueryBatchInfo));
+        ws.qpanels.reserve((size_t)(Qp / 32) * h->ksteps * 64 * sizeof(half8));
+        ws.eps.reserve((size_t)nq * sizeof(float));
+        ws.dense.reserve((size_t)Qp * h->Npad * sizeof(float));
+        ws.fallback.reserve((size_t)nq * sizeof(int32_t));
+        ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
+        QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
+        VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
+        const int64_t total = nq * Dm;
+        query_stats_kernel<<<dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 512)), dim3(256), 0, st>>>(dq, total, info);
+        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0,
+                                                          h->maxnorm2);
+        const int64_t threads = (Qp / 32) * h->ksteps * 64;
+        build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(
+            dq, nq, Dm, D4, h->ksteps, Qp / 32, info, ws.qpanels.as<half8>());
+        EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
+                   h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
+        query_eps_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(ea);
+        const int64_t ntiles = h->Npad / kTileRows;
+        timing_mark(h, tslot, 0, st);
+        {
+            const dim3 grid((unsigned)((ntiles + 3) / 4), (unsigned)(Qp / 64));
+            if (h->ksteps == 4)
+                dense_scores_kernel<4><<<grid, dim3(256), 0, st>>>(h->panels.as<half8>(), h->bias.as<float>(),
+                                                                  ws.qpanels.as<half8>(), info, ntiles, h->Npad,
+                                                                  ws.dense.as<float>());
+            else
+                dense_scores_kernel<8><<<grid, dim3(256), 0, st>>>(h->panels.as<half8>(), h->bias.as<float>(),
+                                                                  ws.qpanels.as<half8>(), info, ntiles, h->Npad,
+                                                                  ws.dense.as<float>());
+        }
+        timing_mark(h, tslot, 1, st);
+        DenseSelectArgs da{};
+        da.c = rc;
+        da.scores = ws.dense.as<float>();
+        da.eps = ws.eps.as<float>();
+        da.info = info;
+        da.nq = nq;
+        da.Npad = h->Npad;
+        da.cand_cap = cand_cap;
+        da.fallback = ws.fallback.as<int32_t>();
+        da.fb_list = ws.fb_list.as<int32_t>();
+        da.fb_count = fb_count;
+        da.stat_counters = stat_counters;
+        da.D = D;
+        da.I = I;
+        da.pkeys = pk;
+        da.pids = pi;
+        {
+            const int kpl = kpl_for(k);
+            const size_t lds = (size_t)(h->Npad + cand_cap) * 4;
+            DISPATCH_KPL(kpl, (dense_select_kernel<KPL><<<dim3((unsigned)nq), dim3(64), lds, st>>>(da)));
+            VDB_HIP(hipGetLastError());
+        }
+        // queries whose candidate list overflowed (or unusable scales): exhaustive exact pass
+        int64_t S = std::min<int64_t>(16, std::max<int64_t>(1, h->N / 1024));
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
+        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
+        ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
+        ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
+        RefineFullArgs fa{};
+        fa.c = rc;
+        fa.qlist = da.fb_list;
+        fa.count_ptr = fb_count;
+        fa.S = (int)S;
+        fa.rows_per_split = (h->N + S - 1) / S;
+        fa.pkeys = ws.pkeys.as<double>();
+        fa.pids = ws.pids.as<int64_t>();
+        launch_refine_full(fa, 1024, st);
+        MergeArgs ma{};
+        ma.pkeys = fa.pkeys;
+        ma.pids = fa.pids;
+        ma.part_stride = k;
+        ma.slot_stride = S * k;
+        ma.nparts = (int)S;
+        ma.k = k;
+        ma.metric = h->metric;
+        ma.qlist = da.fb_list;
+        ma.count_ptr = fb_count;
+        ma.D = D;
+        ma.I = I;
+        ma.okeys = pk;
+        ma.oids = pi;
+        launch_merge(ma, 256, st);
+        timing_mark(h, tslot, 2, st);
+        h->last.last_path = VDB_PATH_MFMA_SCAN;
+        return;
+    }
 
     if (!use_scan) {
         // exhaustive exact scan, split over S waves per query
