@@ -355,12 +355,21 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     if (row1 > end) row1 = end;
                     resc = m2 <= that;
                     cand = !resc;
+                    if (cand) {   // a candidate is a quad of 4 rows: it must not run past the end of its list
+                        const int crow = row0 + quad_row_offset(__float_as_uint(m1));
+                        if (crow + kQuadRows > end) {
+                            cand = false;
+                            resc = true;
+                            row0 = crow;
+                            row1 = end;
+                        }
+                    }
                 }
             }
             const unsigned long long cm = __ballot(cand), rm = __ballot(resc);
             if (cand) {
                 const int pos = ncand + __popcll(cm & lt_mask);
-                if (pos < a.cand_cap) cr[pos] = row0 + (int)(__float_as_uint(m1) & 0xFFu);
+                if (pos < a.cand_cap) cr[pos] = row0 + quad_row_offset(__float_as_uint(m1));
             }
             if (resc) {
                 const int pos = nres + __popcll(rm & lt_mask);

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
     const bool int_exact = a.corpus_int_unscaled && !notint && a.info->sq == 1.f && a.sx == 1.f &&
                            mag * 1.000001 < 16777216.0;
     const double acc_err = int_exact ? 0.0 : (double)(a.Dpad + 3) * ldexp(1.0, -23) * mag;
-    const double pack_err = ldexp(1.0, -15) * mag;
+    const double pack_err = ldexp(1.0, -17) * mag;     // 6 mantissa bits carry the quad id
     const double bias_err = (a.metric == 0 && !int_exact) ? ldexp(1.0, -24) * Xn * Xn : 0.0;
     const double f = (a.metric == 0) ? 2.0 : 1.0;
     const double eps_true = f * dot_err + acc_err + pack_err + bias_err;

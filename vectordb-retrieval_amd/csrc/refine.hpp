@@ -97,7 +97,7 @@ __device__ __forceinline__ void write_topk(const WaveTopK<KPL> &tk, int metric, 
 struct RefineListArgs {
     RefineCommon c;
     int64_t nq;
-    const int32_t *cand_rows;   // [nq][cand_cap] local row numbers
+    const int32_t *cand_rows;   // [nq][cand_cap] first row of each candidate quad (4 consecutive rows)
     const int32_t *rescan_rows; // [nq][rescan_cap][2] row ranges [row0,row1) of the bins to re-scan
     const int32_t *counts;      // [nq][2] {n_cand, n_rescan}
     const int32_t *fallback;    // [nq] 1 -> handled by the exhaustive pass
@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
     ncand = ncand < a.cand_cap ? ncand : a.cand_cap;
     nres = nres < a.rescan_cap ? nres : a.rescan_cap;
     const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
-    for (int base = 0; base < ncand; base += 64) {
+    for (int base = 0; base < ncand * 4; base += 64) {       // a candidate is a quad of 4 consecutive rows
         const int i = base + lane;
-        bool valid = i < ncand;
-        int64_t row = valid ? (int64_t)cr[i] : 0;
+        bool valid = i < ncand * 4;
+        int64_t row = valid ? (int64_t)cr[i >> 2] + (i & 3) : 0;
         valid = valid && row < a.c.N;
         uint64_t key = ~0ull;
         if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);

@@ -47,7 +47,7 @@ struct ScanArgs {
     const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
 };
 
-// (score & ~0xFF) | id  -- one v_and_or_b32 when the mask lives in a VGPR (the id is wave-uniform)
+// (score & ~mask) | id  -- one v_and_or_b32 when the mask lives in a VGPR (the id is wave-uniform)
 __device__ __forceinline__ float pack_score(float v, unsigned mask, unsigned id) {
     return __uint_as_float((__float_as_uint(v) & mask) | id);
 }
@@ -57,6 +57,14 @@ __device__ __forceinline__ float fast_min(float a, float b, float neg_inf) {
 }
 
 // ---- phases of one 32-row tile, for one wave (sched_barrier(0) keeps hipcc from blending them) ----------
+// a packed bin minimum names a quad: offset of its first row inside the bin
+__host__ __device__ inline int quad_row_offset(unsigned packed_bits) {
+    const unsigned id = packed_bits & 0x3Fu;
+    return (int)(((id >> 2) << 4) | ((id & 3u) << 2));
+}
+constexpr unsigned kQuadIdMask = 0xFFFFFFC0u;
+constexpr int kQuadRows = 4;
+
 template <int KSTEPS, int ABL>
 __device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half8 (&b0)[KSTEPS],
                                            const half8 (&b1)[KSTEPS], const float16v &cin, float16v &acc0,
@@ -74,6 +82,12 @@ __device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half
     }
 }
 
+// Select phase of one tile.  The 16 scores a lane holds per column block are 4 QUADS of 4 consecutive corpus
+// rows (registers 4g..4g+3 <-> rows 16t+4g..16t+4g+3 of the bin).  Only the quad minimum enters the running
+// (min, second min) of the bin, tagged with the 6-bit quad id (tile-in-bin*4 + g) in its low mantissa bits:
+// 3 + 1 + 2 = 6 VALU ops per 4 scores (1.5 per score instead of 3), which takes the VALU off the critical path
+// of the matrix pipe.  A candidate is then a quad (4 rows, re-scored exactly), and the bin's second minimum is
+// the second-smallest QUAD minimum: two close scores inside one quad need no re-scan at all.
 template <int ABL>
 __device__ __forceinline__ void select_phase(const float16v &acc0, const float16v &acc1, float (&m1)[2],
                                              float (&m2)[2], unsigned idmask, float neg_inf, unsigned id0) {
@@ -82,11 +96,15 @@ __device__ __forceinline__ void select_phase(const float16v &acc0, const float16
         return;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v0 = pack_score(acc0[r], idmask, id0 + r);
+    for (int g = 0; g < 4; ++g) {
+        const float q0 = fast_min(fast_min(acc0[4 * g], acc0[4 * g + 1], neg_inf),
+                                  fast_min(acc0[4 * g + 2], acc0[4 * g + 3], neg_inf), neg_inf);
+        const float v0 = pack_score(q0, idmask, id0 + g);
         m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
         m1[0] = fast_min(m1[0], v0, neg_inf);
-        const float v1 = pack_score(acc1[r], idmask, id0 + r);
+        const float q1 = fast_min(fast_min(acc1[4 * g], acc1[4 * g + 1], neg_inf),
+                                  fast_min(acc1[4 * g + 2], acc1[4 * g + 3], neg_inf), neg_inf);
+        const float v1 = pack_score(q1, idmask, id0 + g);
         m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
         m1[1] = fast_min(m1[1], v1, neg_inf);
     }
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
     asm volatile("" : "+v"(NEG_INF));  // opaque, or LLVM folds med3(a,b,-inf) back into a canonicalising fmin
-    unsigned idmask = 0xFFFFFF00u;
+    unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));   // pin the mask in a VGPR (a literal cannot ride in VOP3 next to an SGPR id)
     float m1[2] = {INF, INF}, m2[2] = {INF, INF};   // level 1 (current bin)
     float M1[2] = {INF, INF}, M2[2] = {INF, INF};   // level 2 (whole chunk)
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 4));
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2));
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);  // BT % ST == 0
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
                 // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 4));
+                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2));
                 if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
                     flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
-        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 4));  // drain the last tile
+        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2));  // drain the last tile
         flush_bin(span1 - 1, BPS - 1);
     }
     if (ITEMS) return;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
     asm volatile("" : "+v"(NEG_INF));
-    unsigned idmask = 0xFFFFFF00u;
+    unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));
     float m1 = INF, m2 = INF, M1 = INF, M2 = INF;
     int Ms = 0;
@@ -434,10 +452,12 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
         }
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-            const unsigned id0 = (unsigned)((half * HT + t) * 16);
+            const unsigned id0 = (unsigned)((half * HT + t) * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = pack_score(acc[t][r], idmask, id0 + r);
+            for (int g = 0; g < 4; ++g) {       // quad minima, as in select_phase
+                const float qm = fast_min(fast_min(acc[t][4 * g], acc[t][4 * g + 1], NEG_INF),
+                                          fast_min(acc[t][4 * g + 2], acc[t][4 * g + 3], NEG_INF), NEG_INF);
+                const float v = pack_score(qm, idmask, id0 + g);
                 m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
                 m1 = fast_min(m1, v, NEG_INF);
             }
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             if (single) {
                 const int pos = ncand + __popcll(smask & lt_mask);
                 const int hh = s & 1;
-                const int row = sspan * kSpanRows + hh * kBinRows + (int)(__float_as_uint(m1) & 0xFFu);
+                const int row = sspan * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(m1));
                 if (pos < a.cand_cap) cr[pos] = row;
             }
             ncand += __popcll(smask);
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if (cand) {
                         const int pos = ncand + __popcll(cm & lt_mask);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + (int)(__float_as_uint(bm1) & 0xFFu));
+                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
@@ -650,7 +670,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
-                    cr[pos] = spanv[e] * kSpanRows + hh * kBinRows + (int)(__float_as_uint(m1) & 0xFFu);
+                    cr[pos] = spanv[e] * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(m1));
             } else {               // two or more interesting scores: walk the level-1 bins of this superbin
                 const int chunk = s >> 1;
                 const int64_t sp0 = (int64_t)chunk * a.spans_per_chunk;
@@ -669,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                     } else {
                         const int pos = atomicAdd(cnt_c, 1);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + (int)(__float_as_uint(bm1) & 0xFFu));
+                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                     }
                 }
             }
