@@ -33,7 +33,8 @@ struct ScanArgs {
     float *sb_m2;          // [nchunks*2][Qpad] second-smallest score of the superbin
     int32_t *sb_span;      // [nchunks*2][Qpad] span holding the superbin minimum
     int64_t nspans;        // total spans (Npad / 512)
-    int spans_per_chunk;
+    int spans_per_chunk;   // base chunk length; the first `chunk_rem` chunks are one span longer
+    int chunk_rem;
     int nchunks;
     int nqtiles;           // query tiles (64 * NWAVES queries each)
     int64_t Qpad;          // multiple of 512
@@ -58,6 +59,12 @@ __device__ __forceinline__ float fast_min(float a, float b, float neg_inf) {
 
 // ---- phases of one 32-row tile, for one wave (sched_barrier(0) keeps hipcc from blending them) ----------
 // a packed bin minimum names a quad: offset of its first row inside the bin
+// chunk c covers spans [chunk_span0(c), chunk_span0(c+1)): nspans are dealt as evenly as possible so that the
+// workgroup count is a multiple of 8 x (query tiles) and every XCD gets the same amount of work
+__host__ __device__ inline int64_t chunk_span0(int chunk, int spc, int rem) {
+    return (int64_t)chunk * spc + (chunk < rem ? chunk : rem);
+}
+
 __host__ __device__ inline int quad_row_offset(unsigned packed_bits) {
     const unsigned id = packed_bits & 0x3Fu;
     return (int)(((id >> 2) << 4) | ((id & 3u) << 2));
@@ -171,8 +178,8 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         chunk = x + 8 * ci;
         if (chunk >= a.nchunks) return;
         q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;       // first query of this wave
-        span0 = (int64_t)chunk * a.spans_per_chunk;
-        span1 = span0 + a.spans_per_chunk;
+        span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+        span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
         if (span1 > a.nspans) span1 = a.nspans;
         out_pitch = a.Qpad;
         out_col = q0 + (lane & 31);
@@ -374,8 +381,8 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
     const float cs = a.info->cs;
     const half8 *qp = a.qpanels + (size_t)(q0 / 32) * KS * 64 + lane;   // this wave's B panel
 
-    const int64_t span0 = (int64_t)chunk * a.spans_per_chunk;
-    int64_t span1 = span0 + a.spans_per_chunk;
+    const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+    int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
     const int npass = (int)(span1 - span0) * 2;
     const int nsteps = npass * nK;                          // K-steps over the whole chunk
@@ -490,7 +497,7 @@ struct SelectArgs {
     const float *eps;            // [nq]
     const QueryBatchInfo *info;
     int64_t nq, Qpad, nspans, N;
-    int spans_per_chunk, nchunks, k;
+    int spans_per_chunk, chunk_rem, nchunks, k;
     int cand_cap, rescan_cap;
     int32_t *cand_rows;          // [nq][cand_cap]
     int32_t *rescan_rows;        // [nq][rescan_cap]
@@ -561,8 +568,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                 dmask &= dmask - 1;
                 const int sb = e * 64 + src;
                 const int chunk = sb >> 1, hh = sb & 1;
-                const int64_t sp0 = (int64_t)chunk * a.spans_per_chunk;
-                int64_t sp1 = sp0 + a.spans_per_chunk;
+                const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+                int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
                 if (sp1 > a.nspans) sp1 = a.nspans;
                 for (int64_t base = sp0; base < sp1; base += 64) {
                     const int64_t sp = base + lane;
@@ -673,8 +680,8 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                     cr[pos] = spanv[e] * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(m1));
             } else {               // two or more interesting scores: walk the level-1 bins of this superbin
                 const int chunk = s >> 1;
-                const int64_t sp0 = (int64_t)chunk * a.spans_per_chunk;
-                int64_t sp1 = sp0 + a.spans_per_chunk;
+                const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+                int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
                 if (sp1 > a.nspans) sp1 = a.nspans;
                 for (int64_t sp = sp0; sp < sp1; ++sp) {
                     const size_t o = (size_t)(sp * 2 + hh) * a.Qpad + q;

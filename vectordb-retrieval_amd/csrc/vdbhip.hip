@@ -218,7 +218,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
 struct ScanGeom {
     bool ok = false;
     int64_t nspans = 0;
-    int spc = 0, nchunks = 0, vpl = 0;
+    int spc = 0, rem = 0, nchunks = 0, vpl = 0;
 };
 
 ScanGeom scan_geometry(const vdb_index_s *h, int k) {
@@ -232,8 +232,16 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : 16, spc_hi);
     spc = std::max<int64_t>(spc, spc_lo);
     if (spc < 2 && g.nspans >= 64) spc = std::min<int64_t>(2, spc_hi);
-    g.spc = (int)spc;
-    g.nchunks = (int)((g.nspans + spc - 1) / spc);
+    int64_t nchunks = (g.nspans + spc - 1) / spc;
+    // deal the spans evenly over a multiple of 8 chunks (one XCD label each, see scan_kernel) when possible
+    if (nchunks >= 16) {
+        int64_t n8 = (nchunks + 7) / 8 * 8;
+        if (n8 <= 512 && g.nspans / n8 >= 1) nchunks = n8;   // (more chunks only add superbins)
+    }
+    g.nchunks = (int)nchunks;
+    g.spc = (int)(g.nspans / nchunks);
+    g.rem = (int)(g.nspans - (int64_t)g.spc * nchunks);
+    if (g.spc < 1) return g;
     const int nsb = 2 * g.nchunks;
     g.vpl = 1;
     while (g.vpl * 64 < nsb) g.vpl *= 2;
@@ -246,8 +254,8 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
 // production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
 // ablations of variant 0 and return wrong results).
 struct ScanVariant { int nwaves, st, wps; };
-constexpr ScanVariant kScanVariants[] = {{8, 2, 2}, {8, 4, 2}, {4, 4, 2}, {4, 2, 2}, {8, 2, 2}, {8, 2, 2}, {8, 2, 2},
-                                         {8, 2, 2}, {8, 2, 2}, {8, 2, 2}};
+constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {8, 2, 2}, {4, 4, 2}, {4, 2, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2},
+                                         {8, 4, 2}, {8, 4, 2}, {8, 4, 2}};
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
 template <int KSTEPS>
@@ -256,13 +264,13 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
     const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
     switch (variant) {
-        case 1: scan_kernel<KSTEPS, 8, 4, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 1: scan_kernel<KSTEPS, 8, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 2: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
         case 3: scan_kernel<KSTEPS, 4, 2, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
-        case 7: scan_kernel<KSTEPS, 8, 2, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 8: scan_kernel<KSTEPS, 8, 2, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 9: scan_kernel<KSTEPS, 8, 2, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        default: scan_kernel<KSTEPS, 8, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 7: scan_kernel<KSTEPS, 8, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 8: scan_kernel<KSTEPS, 8, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 9: scan_kernel<KSTEPS, 8, 4, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        default: scan_kernel<KSTEPS, 8, 4, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
     }
 }
 
@@ -521,6 +529,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     sa.sb_span = ws.sb_span.as<int32_t>();
     sa.nspans = g.nspans;
     sa.spans_per_chunk = g.spc;
+    sa.chunk_rem = g.rem;
     sa.nchunks = g.nchunks;
     sa.Qpad = Qpad;
     timing_mark(h, tslot, 0, st);
@@ -540,6 +549,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.nspans = g.nspans;
     se.N = h->N;
     se.spans_per_chunk = g.spc;
+    se.chunk_rem = g.rem;
     se.nchunks = g.nchunks;
     se.k = k;
     se.cand_cap = cand_cap;
