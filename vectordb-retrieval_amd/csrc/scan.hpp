@@ -618,25 +618,26 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
 }
 
-// ---- select, coalesced form: 16 queries per wave, 4 lanes per query ----------------------------------
+// ---- select, multi-lane form: LPQ lanes per query, 64/LPQ queries per wave ----------------------------------
 // The superbin arrays are [superbin][query]: for one superbin row the 16 queries of a wave are one 64-byte
 // segment, so every lane-instruction reads whole sectors (the one-wave-per-query form above strides by
 // Qpad*4 bytes and is latency bound).  Lane (qi = lane>>2, part = lane&3) keeps superbins part, part+4, ...
 // of query qi in registers; counts are reduced over the 4 lanes with two shuffles.  Work lists are appended
 // through per-query LDS counters.
-template <int V>
+template <int V, int LPQ>
 __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
-    __shared__ int s_cnt[4][16][2];
+    constexpr int QPW = 64 / LPQ;
+    __shared__ int s_cnt[4][QPW][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qi = lane >> 2, part = lane & 3;
-    const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * 16 + qi;   // < Qpad by construction of the grid
+    const int qi = lane / LPQ, part = lane % LPQ;
+    const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QPW + qi;   // < Qpad by construction of the grid
     const bool qvalid = q < a.nq;
     const int nsb = a.nchunks * 2;
     if (part < 2) s_cnt[wave][qi][part] = 0;
     unsigned v[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        const int s = e * 4 + part;
+        const int s = e * LPQ + part;
         v[e] = (s < nsb) ? sortable_u32(a.sb_m1[(size_t)s * a.Qpad + q]) : 0xFFFFFFFFu;
     }
     unsigned ans = 0;
@@ -645,8 +646,8 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
         int cnt = 0;
 #pragma unroll
         for (int e = 0; e < V; ++e) cnt += (v[e] <= trial) ? 1 : 0;
-        cnt += __shfl_xor(cnt, 1);
-        cnt += __shfl_xor(cnt, 2);
+#pragma unroll
+        for (int o = 1; o < LPQ; o <<= 1) cnt += __shfl_xor(cnt, o);
         if (cnt < a.k) ans |= (1u << bit);
     }
     const float tau = unsortable_f32(ans);
@@ -662,14 +663,14 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
         int spanv[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int s = e * 4 + part;
+            const int s = e * LPQ + part;
             const bool act = (s < nsb) && (unsortable_f32(v[e]) <= that);
             sm2v[e] = act ? a.sb_m2[(size_t)s * a.Qpad + q] : __builtin_inff();
             spanv[e] = act ? a.sb_span[(size_t)s * a.Qpad + q] : 0;
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int s = e * 4 + part;
+            const int s = e * LPQ + part;
             if (s >= nsb) continue;
             const float m1 = unsortable_f32(v[e]);
             if (!(m1 <= that)) continue;

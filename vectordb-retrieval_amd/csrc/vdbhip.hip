@@ -562,14 +562,14 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
     const int nsb_i = 2 * g.nchunks;
-    if (nsb_i <= 256 && h->select_variant == 0) {  // coalesced form: 16 queries per wave
-        const unsigned sgrid = (unsigned)((nq + 63) / 64);
+    if (nsb_i <= 256 && h->select_variant == 0) {  // multi-lane form: 16 lanes per query, 4 queries per wave
+        const unsigned sgrid = (unsigned)((nq + 15) / 16);
         if (nsb_i <= 64)
-            select_kernel_v2<16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+            select_kernel_v2<4, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
         else if (nsb_i <= 128)
-            select_kernel_v2<32><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+            select_kernel_v2<8, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
         else
-            select_kernel_v2<64><<<dim3(sgrid), dim3(256), 0, st>>>(se);
+            select_kernel_v2<16, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
     } else {
         switch (g.vpl) {
             case 1: launch_select<1>(se, st); break;
