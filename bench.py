@@ -136,24 +136,21 @@ def main() -> None:
     I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
     sharded = world > 1 or os.environ.get("VDBHIP_BENCH_FORCE_SHARDED") == "1"   # (rehearsal of the N>1 code path)
     if sharded:
-        my_keys = torch.empty((nq, k), dtype=torch.float64, device=dev)
-        my_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        all_keys = torch.empty((world, nq, k), dtype=torch.float64, device=dev)
-        all_ids = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        # one packed buffer per rank: keys (nq*k float64) immediately followed by ids (nq*k int64) -> ONE all-gather
+        my_pack = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
+        all_pack = torch.empty((world, 2, nq, k), dtype=torch.int64, device=dev)
 
     def step():
         if not sharded:
             index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
         else:
-            index.search_partial_device(q_t.data_ptr(), nq, k, my_keys.data_ptr(), my_ids.data_ptr(), stream)
+            index.search_partial_device(q_t.data_ptr(), nq, k, my_pack[0].data_ptr(), my_pack[1].data_ptr(), stream)
             if world > 1:
-                dist.all_gather_into_tensor(all_keys, my_keys)
-                dist.all_gather_into_tensor(all_ids, my_ids)
+                dist.all_gather_into_tensor(all_pack, my_pack)
             else:
-                all_keys.copy_(my_keys.unsqueeze(0))
-                all_ids.copy_(my_ids.unsqueeze(0))
-            vdbhip.merge_partials_device(metric, local_rank, all_keys.data_ptr(), all_ids.data_ptr(), world, nq, k,
-                                         D_t.data_ptr(), I_t.data_ptr(), stream)
+                all_pack.copy_(my_pack.unsqueeze(0))
+            vdbhip.merge_packed_partials_device(metric, local_rank, all_pack.data_ptr(), world, nq, k,
+                                                D_t.data_ptr(), I_t.data_ptr(), stream)
 
     def fence():
         torch.cuda.synchronize()

@@ -107,6 +107,11 @@ int vdb_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, int 
 int vdb_merge_partials_device(int metric, int device, const double *keys_dev, const int64_t *ids_dev, int nparts,
                               int64_t nq, int k, float *D_dev, int64_t *I_dev, void *stream);
 
+/* same merge for ONE packed buffer per part -- what a single RCCL all-gather produces when every rank sends
+ * its keys (nq*k doubles) immediately followed by its ids (nq*k int64): layout (nparts, 2, nq, k) 8-byte words. */
+int vdb_merge_packed_partials_device(int metric, int device, const void *packed_dev, int nparts, int64_t nq, int k,
+                                     float *D_dev, int64_t *I_dev, void *stream);
+
 /* ---- IVF-Flat -- replaces faiss.index_factory(d, "IVF<nlist>,Flat", metric) + train/add/search
  *      (modular.py:277-286, 437-441, 544; approximate_search.py:39-51, 87) ------------------- */
 /* k-means (Lloyd) on at most max_points_per_centroid*nlist rows sampled with `seed`; niter iterations. */

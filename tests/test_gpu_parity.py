@@ -316,6 +316,14 @@ def test_sharded_partials_merge_is_shard_count_invariant(vdb, oracle):
             torch.cuda.synchronize()
             np.testing.assert_array_equal(I.cpu().numpy(), Io)
             np.testing.assert_array_equal(D.cpu().numpy(), Do)
+            # packed form: what ONE all-gather of [keys | ids] per rank produces
+            packed = torch.stack([torch.stack([keys[p].view(torch.int64), ids[p]]) for p in range(parts)]).contiguous()
+            D.zero_()
+            I.zero_()
+            vdb.merge_packed_partials_device(metric, 0, packed.data_ptr(), parts, 128, k, D.data_ptr(), I.data_ptr())
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(I.cpu().numpy(), Io)
+            np.testing.assert_array_equal(D.cpu().numpy(), Do)
             for s in shards:
                 s.close()
 

@@ -48,10 +48,12 @@ class _OracleEngine:
             ids = np.full((len(qn), k), -1, np.int64)
         else:
             _, ids, keys = self.o.knn(self.x, qn, k, self.metric, id_base=self.id_base, return_keys=True)
-        return self.torch.from_numpy(keys), self.torch.from_numpy(ids)
+        return self.torch.from_numpy(np.stack([keys.view(np.int64), ids]))      # packed (2, nq, k)
 
-    def merge(self, keys_all, ids_all):
-        return self.o.merge_partials(keys_all.numpy(), ids_all.numpy(), self.metric)
+    def merge(self, all_pack):
+        a = all_pack.numpy()
+        return self.o.merge_partials(np.ascontiguousarray(a[:, 0]).view(np.float64), np.ascontiguousarray(a[:, 1]),
+                                     self.metric)
 
 
 def _worker(rank, world, port, out_dir):

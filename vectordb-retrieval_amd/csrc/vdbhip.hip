@@ -837,6 +837,30 @@ int vdb_merge_partials_device(int metric, int device, const double *keys_dev, co
     });
 }
 
+int vdb_merge_packed_partials_device(int metric, int device, const void *packed_dev, int nparts, int64_t nq, int k,
+                                     float *D_dev, int64_t *I_dev, void *stream) {
+    return guarded([&] {
+        if (metric != VDB_METRIC_L2 && metric != VDB_METRIC_IP) throw Error(VDB_ERR_INVALID, "unknown metric");
+        if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+        if (nparts < 0 || nq < 0) throw Error(VDB_ERR_INVALID, "negative size");
+        if (nq == 0) return;
+        if (!D_dev || !I_dev || (nparts > 0 && !packed_dev)) throw Error(VDB_ERR_INVALID, "null pointer");
+        set_device(device);
+        MergeArgs ma{};
+        ma.pkeys = reinterpret_cast<const double *>(packed_dev);
+        ma.pids = reinterpret_cast<const int64_t *>(packed_dev) + nq * k;
+        ma.part_stride = 2 * nq * k;
+        ma.slot_stride = k;
+        ma.nparts = nparts;
+        ma.k = k;
+        ma.metric = metric;
+        ma.count = nq;
+        ma.D = D_dev;
+        ma.I = I_dev;
+        launch_merge(ma, nq, as_stream(stream));
+    });
+}
+
 int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
     return guarded([&] {
         auto *h = check(hh);

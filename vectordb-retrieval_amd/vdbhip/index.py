@@ -105,3 +105,10 @@ def merge_partials_device(metric: str, device: int, keys_ptr: int, ids_ptr: int,
     """Merge (nparts, nq, k) per-shard partial lists (device memory) into the final (nq, k) result."""
     _ffi.check(_ffi.load().vdb_merge_partials_device(_METRICS[metric], int(device), keys_ptr, ids_ptr, int(nparts),
                                                      int(nq), int(k), d_ptr, i_ptr, stream or None))
+
+
+def merge_packed_partials_device(metric: str, device: int, packed_ptr: int, nparts: int, nq: int, k: int, d_ptr: int,
+                                 i_ptr: int, stream: int = 0) -> None:
+    """Merge per-part packed buffers (nparts, 2, nq, k) of 8-byte words: keys then ids (one all-gather)."""
+    _ffi.check(_ffi.load().vdb_merge_packed_partials_device(_METRICS[metric], int(device), packed_ptr, int(nparts),
+                                                            int(nq), int(k), d_ptr, i_ptr, stream or None))

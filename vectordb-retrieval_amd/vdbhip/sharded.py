@@ -3,8 +3,8 @@
 The reference has no distributed code; this is the MI355X-native scaling path of its brute-force
 hot path.  Rank r of W keeps rows [r*ceil(N/W), min(N, (r+1)*ceil(N/W))) in its own HBM, every
 rank scans its shard for the SAME query batch, the per-shard partial top-k (float64 order keys + global ids,
-`vdb_search_partial_device`) are exchanged with one all-gather each, and every rank merges them with
-`vdb_merge_partials_device`.  The merge key (float64 key, id) makes the result independent of W.
+`vdb_search_partial_device`, packed into one buffer) are exchanged with ONE all-gather, and every rank merges
+them with `vdb_merge_packed_partials_device`.  The merge key (float64 key, id) makes the result independent of W.
 
 The collective and the shard arithmetic live here; the per-shard engine is pluggable so the N > 1 plumbing is
 testable on CPU with the gloo backend (tests/test_sharded_gloo.py injects a CPU engine built on the oracle --
@@ -48,42 +48,39 @@ class HipShardEngine:
         return self.torch.from_numpy(q).to(self.dev)
 
     def search_partial(self, q_dev, k: int):
+        """Packed partial of this shard: int64 tensor (2, nq, k) = [float64 keys (bit pattern) | ids]."""
         t = self.torch
         nq = q_dev.shape[0]
-        keys = t.empty((nq, k), dtype=t.float64, device=self.dev)
-        ids = t.empty((nq, k), dtype=t.int64, device=self.dev)
-        self.index.search_partial_device(q_dev.data_ptr(), nq, k, keys.data_ptr(), ids.data_ptr(),
+        pack = t.empty((2, nq, k), dtype=t.int64, device=self.dev)
+        self.index.search_partial_device(q_dev.data_ptr(), nq, k, pack[0].data_ptr(), pack[1].data_ptr(),
                                          t.cuda.current_stream().cuda_stream)
-        return keys, ids
+        return pack
 
-    def merge(self, keys_all, ids_all) -> Tuple[np.ndarray, np.ndarray]:
-        from .index import merge_partials_device
+    def merge(self, all_pack) -> Tuple[np.ndarray, np.ndarray]:
+        from .index import merge_packed_partials_device
 
         t = self.torch
-        parts, nq, k = keys_all.shape
+        parts, _, nq, k = all_pack.shape
         D = t.empty((nq, k), dtype=t.float32, device=self.dev)
         I = t.empty((nq, k), dtype=t.int64, device=self.dev)
-        merge_partials_device(self.metric, self.device, keys_all.data_ptr(), ids_all.data_ptr(), parts, nq, k,
-                              D.data_ptr(), I.data_ptr(), t.cuda.current_stream().cuda_stream)
+        merge_packed_partials_device(self.metric, self.device, all_pack.data_ptr(), parts, nq, k, D.data_ptr(),
+                                     I.data_ptr(), t.cuda.current_stream().cuda_stream)
         return D.cpu().numpy(), I.cpu().numpy()
 
 
-def all_gather_partials(keys, ids, world: int):
-    """(nq,k) per rank -> (world, nq, k) on every rank.  RCCL over xGMI when the tensors are on GPUs."""
+def all_gather_partials(pack, world: int):
+    """(2, nq, k) per rank -> (world, 2, nq, k) on every rank: ONE collective (RCCL over xGMI for GPU tensors)."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
-        return keys.unsqueeze(0), ids.unsqueeze(0)
-    keys_all = torch.empty((world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
-    ids_all = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-    if keys.is_cuda:
-        dist.all_gather_into_tensor(keys_all, keys.contiguous())
-        dist.all_gather_into_tensor(ids_all, ids.contiguous())
+        return pack.unsqueeze(0)
+    out = torch.empty((world,) + tuple(pack.shape), dtype=pack.dtype, device=pack.device)
+    if pack.is_cuda:
+        dist.all_gather_into_tensor(out, pack.contiguous())
     else:  # gloo
-        dist.all_gather(list(keys_all.unbind(0)), keys.contiguous())
-        dist.all_gather(list(ids_all.unbind(0)), ids.contiguous())
-    return keys_all, ids_all
+        dist.all_gather(list(out.unbind(0)), pack.contiguous())
+    return out
 
 
 class HipShardedExactSearch(BaseAlgorithm):
@@ -130,9 +127,8 @@ class HipShardedExactSearch(BaseAlgorithm):
         q = _ffi.as_f32_c(queries)
         if q.ndim == 1:
             q = q.reshape(1, -1)
-        keys, ids = self.engine.search_partial(self.engine.to_device(q), int(k))
-        keys_all, ids_all = all_gather_partials(keys, ids, self.world)
-        return self.engine.merge(keys_all, ids_all)
+        pack = self.engine.search_partial(self.engine.to_device(q), int(k))
+        return self.engine.merge(all_gather_partials(pack, self.world))
 
     def search(self, query: np.ndarray, k: int = 10) -> SearchResult:
         d, i = self.batch_search(np.asarray(query, dtype=np.float32).reshape(1, -1), k)
