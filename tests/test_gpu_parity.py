@@ -142,6 +142,7 @@ CASES = [
     (40000, 128, 200, 10, "ip", "gauss"),
     (50000, 50, 130, 10, "ip", "glove"),
     (33000, 64, 64, 1, "l2", "gauss"),
+    (60000, 96, 3, 10, "ip", "gauss"),       # tiny batch, still the MFMA pipeline
     (70000, 16, 100, 20, "l2", "gauss"),
     (100000, 100, 96, 100, "l2", "gauss"),   # k too large for the bin select at this N: exact kernel
     (120000, 100, 96, 100, "l2", "gauss"),   # k = 100 through the MFMA scan
@@ -174,7 +175,7 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     # the bin select needs the superbins (two per >=512-row chunk) to outnumber k four to one
-    if n >= 32768 and nq >= 64 and (n + 511) // 512 >= 2 * k:
+    if n >= 32768 and (n + 511) // 512 >= 2 * k:
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st
     elif n <= 8192 and nq >= 64 and d <= 128 and 2 * k <= n:

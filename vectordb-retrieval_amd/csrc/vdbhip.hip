@@ -331,7 +331,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     ScanGeom g;
     bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
     if (use_scan) g = scan_geometry(h, k);
-    use_scan = use_scan && g.ok && (h->force_path == 2 || (nq >= 64 && h->N >= 32768));
+    // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
+    //  needs ~0.07 ms per query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
+    use_scan = use_scan && g.ok && (h->force_path == 2 || h->N >= 32768);
 
     ws.small.reserve(64);
     VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
