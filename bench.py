@@ -65,19 +65,20 @@ def make_data(name: str, rank: int):
     return np.ascontiguousarray(X, np.float32), np.ascontiguousarray(Q, np.float32), k, metric
 
 
-def cpu_baseline(X, Q, k, metric, gpu_ids, budget_s=12.0):
+def cpu_baseline(X, Q, k, metric, gpu_ids, budget_s=15.0):
     """Time the CPU port (oracle/knn_oracle.c, MODE_GEMM32, all host cores) on a bounded query sample and
     use its ids to check the GPU result of the same queries."""
     from oracle import c_oracle
 
     c_oracle.build()
     cores = c_oracle.num_threads()
-    probe = min(32, len(Q))
+    probe = min(len(Q), 8 * cores)                       # enough query blocks to occupy every thread
     t0 = time.perf_counter()
     c_oracle.knn(X, Q[:probe], k, metric, mode=c_oracle.MODE_GEMM32)
     dt = time.perf_counter() - t0
     sample = int(min(len(Q), max(probe, probe * budget_s / max(dt, 1e-6))))
-    sample = max(cores, sample // cores * cores) if sample >= cores else sample
+    sample = max(8 * cores, sample // (8 * cores) * (8 * cores)) if sample >= 8 * cores else sample
+    sample = min(sample, len(Q))
     t0 = time.perf_counter()
     _, ids = c_oracle.knn(X, Q[:sample], k, metric, mode=c_oracle.MODE_GEMM32)
     dt = time.perf_counter() - t0
