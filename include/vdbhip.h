@@ -112,6 +112,16 @@ int vdb_merge_partials_device(int metric, int device, const double *keys_dev, co
 int vdb_merge_packed_partials_device(int metric, int device, const void *packed_dev, int nparts, int64_t nq, int k,
                                      float *D_dev, int64_t *I_dev, void *stream);
 
+/* ---- candidate re-scoring -- replaces the per-query NumPy loop of FaissSearcher._batch_search_lsh_rerank
+ *      (modular.py:483-532: gather candidate rows by id -> exact L2 / inner product -> top-k) and
+ *      LSHSearcher._compute_distances (lsh.py:242-250) ------------------------------------------------ */
+/* cand (nq, ncand) int64 row ids (id_base-relative ids as returned by search; -1 = empty slot, ids of one
+ * query must be distinct).  Output: the k best candidates of every query, flat conventions and padding. */
+int vdb_rerank(vdb_handle h, const float *q_host, int64_t nq, const int64_t *cand_host, int ncand, int k, float *D,
+               int64_t *I);
+int vdb_rerank_device(vdb_handle h, const float *q_dev, int64_t nq, const int64_t *cand_dev, int ncand, int k,
+                      float *D_dev, int64_t *I_dev, void *stream);
+
 /* ---- IVF-Flat -- replaces faiss.index_factory(d, "IVF<nlist>,Flat", metric) + train/add/search
  *      (modular.py:277-286, 437-441, 544; approximate_search.py:39-51, 87) ------------------- */
 /* k-means (Lloyd) on at most max_points_per_centroid*nlist rows sampled with `seed`; niter iterations. */

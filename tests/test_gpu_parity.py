@@ -359,3 +359,33 @@ def test_sharded_algorithm_single_rank(vdb, oracle):
     np.testing.assert_array_equal(i, io)
     np.testing.assert_array_equal(d, do)
     assert a.shard == (0, 50000)
+
+
+def test_candidate_rerank_matches_reference_loop(vdb):
+    """FaissSearcher._batch_search_lsh_rerank (modular.py:483-532) restated in NumPy vs the batched HIP rerank."""
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((5000, 40)).astype(np.float32)
+    Q = rng.standard_normal((37, 40)).astype(np.float32)
+    C, k = 90, 7
+    cand = np.stack([rng.choice(5000, C, replace=False) for _ in range(37)]).astype(np.int64)
+    cand[rng.random(cand.shape) < 0.3] = -1              # FAISS pads missing candidates with -1
+    cand[5] = -1                                          # a query without any candidate
+    cand[6, 3:] = -1                                      # fewer candidates than k
+    for metric in ("l2", "ip"):
+        idx = vdb.FlatIndex(40, metric, 0)
+        idx.add(X)
+        d, i = vdb.rerank_candidates(idx, Q, cand, k, metric)
+        assert d.dtype == np.float32 and i.dtype == np.int64
+        for r in range(37):
+            valid = cand[r][cand[r] >= 0]
+            if metric == "l2":
+                sc = np.sum((X[valid].astype(np.float64) - Q[r].astype(np.float64)) ** 2, axis=1)
+            else:
+                sc = -(X[valid].astype(np.float64) @ Q[r].astype(np.float64))
+            order = np.lexsort((valid, sc))[:k]
+            n = len(order)
+            np.testing.assert_array_equal(i[r, :n], valid[order])
+            want = np.sqrt(sc[order]) if metric == "l2" else sc[order]
+            np.testing.assert_allclose(d[r, :n], want, rtol=2e-6, atol=1e-6)
+            assert np.all(i[r, n:] == -1) and np.all(np.isinf(d[r, n:]))
+        idx.close()

@@ -139,6 +139,39 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
                     a.pids ? a.pids + o : nullptr);
 }
 
+// ---- rerank mode: explicit candidate ids per query ---------------------------------------------------
+struct RerankArgs {
+    RefineCommon c;
+    int64_t nq;
+    const int64_t *cand;   // [nq][ncand] ids (id_base + row), -1 = empty
+    int ncand;
+    float *D;
+    int64_t *I;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (q >= a.nq) return;
+    const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+    WaveTopK<KPL> tk;
+    tk.init(a.c.k);
+    const int64_t *cr = a.cand + (size_t)q * a.ncand;
+    for (int base = 0; base < a.ncand; base += 64) {
+        const int i = base + lane;
+        bool valid = i < a.ncand;
+        const int64_t id = valid ? cr[i] : -1;
+        const int64_t row = id - a.c.id_base;
+        valid = valid && id >= 0 && row >= 0 && row < a.c.N;
+        uint64_t key = ~0ull;
+        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        tk.offer(key, id, valid);
+    }
+    const size_t o = (size_t)q * a.c.k;
+    write_topk<KPL>(tk, a.c.metric, a.D + o, a.I + o, nullptr, nullptr);
+}
+
 // ---- exhaustive mode: every row of the shard, split over S waves per query -----------------------
 struct RefineFullArgs {
     RefineCommon c;

@@ -863,6 +863,74 @@ int vdb_merge_packed_partials_device(int metric, int device, const void *packed_
     });
 }
 
+namespace {
+void rerank_device_impl(vdb_index_s *h, const float *dq, int64_t nq, const int64_t *cand, int ncand, int k, float *D,
+                        int64_t *I, hipStream_t st) {
+    if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
+    if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+    if (nq < 0 || ncand < 0) throw Error(VDB_ERR_INVALID, "negative size");
+    if (nq == 0) return;
+    if (!dq || !D || !I || (ncand > 0 && !cand)) throw Error(VDB_ERR_INVALID, "null pointer");
+    const float *qpad = dq;
+    if (h->D4 != h->dim) {
+        h->ws.qpad.reserve((size_t)nq * h->D4 * sizeof(float));
+        pad_rows_kernel<<<dim3((unsigned)((nq * h->D4 + 255) / 256)), dim3(256), 0, st>>>(dq, nq, h->dim, h->D4,
+                                                                                        h->ws.qpad.as<float>());
+        qpad = h->ws.qpad.as<float>();
+    }
+    RerankArgs a{};
+    a.c = RefineCommon{h->x32.as<float>(), qpad, h->N, h->id_base, h->D4, h->metric, k, nullptr};
+    a.nq = nq;
+    a.cand = cand;
+    a.ncand = ncand;
+    a.D = D;
+    a.I = I;
+    const int kpl = kpl_for(k);
+    DISPATCH_KPL(kpl, (rerank_kernel<KPL><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st>>>(a)));
+    VDB_HIP(hipGetLastError());
+}
+}  // namespace
+
+int vdb_rerank_device(vdb_handle hh, const float *q_dev, int64_t nq, const int64_t *cand_dev, int ncand, int k,
+                      float *D_dev, int64_t *I_dev, void *stream) {
+    return guarded([&] {
+        auto *h = check(hh);
+        set_device(h->device);
+        rerank_device_impl(h, q_dev, nq, cand_dev, ncand, k, D_dev, I_dev, as_stream(stream));
+    });
+}
+
+int vdb_rerank(vdb_handle hh, const float *q_host, int64_t nq, const int64_t *cand_host, int ncand, int k, float *D,
+               int64_t *I) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
+        if (nq <= 0) {
+            if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
+            return;
+        }
+        if (!q_host || !D || !I || (ncand > 0 && !cand_host) || ncand < 0) throw Error(VDB_ERR_INVALID, "bad argument");
+        if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
+        set_device(h->device);
+        Workspace &ws = h->ws;
+        DevBuf dc;
+        ws.stage_q.reserve((size_t)nq * h->dim * sizeof(float));
+        ws.stage_d.reserve((size_t)nq * k * sizeof(float));
+        ws.stage_i.reserve((size_t)nq * k * sizeof(int64_t));
+        dc.reserve((size_t)nq * std::max(ncand, 1) * sizeof(int64_t));
+        hipStream_t st = nullptr;
+        VDB_HIP(hipMemcpyAsync(ws.stage_q.p, q_host, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
+        if (ncand > 0)
+            VDB_HIP(hipMemcpyAsync(dc.p, cand_host, (size_t)nq * ncand * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        rerank_device_impl(h, ws.stage_q.as<float>(), nq, dc.as<int64_t>(), ncand, k, ws.stage_d.as<float>(),
+                           ws.stage_i.as<int64_t>(), st);
+        VDB_HIP(hipMemcpyAsync(D, ws.stage_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipMemcpyAsync(I, ws.stage_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        dc.release();
+    });
+}
+
 int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
     return guarded([&] {
         auto *h = check(hh);

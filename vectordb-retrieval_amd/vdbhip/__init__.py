@@ -6,7 +6,7 @@ Importing the package does not touch the GPU and does not import torch; the shar
 from .plugin_api import (ALGORITHM_REGISTRY, INDEXER_REGISTRY, SEARCHER_REGISTRY, BaseAlgorithm, BaseIndexer,
                          BaseSearcher, CompositeAlgorithm, IndexArtifact, get_algorithm_instance, get_indexer_class,
                          get_searcher_class, register_algorithm, register_indexer, register_searcher)
-from .algorithms import HipBruteForceIndexer, HipExactSearch, HipLinearSearcher
+from .algorithms import HipBruteForceIndexer, HipExactSearch, HipLinearSearcher, rerank_candidates
 from .index import FlatIndex, merge_packed_partials_device, merge_partials_device
 from .ivf import HipApproximateSearch, HipIVFIndexer, HipIVFSearcher, IVFFlatIndex
 from .sharded import HipShardedExactSearch, shard_bounds
@@ -15,6 +15,6 @@ __all__ = [
     "ALGORITHM_REGISTRY", "INDEXER_REGISTRY", "SEARCHER_REGISTRY", "BaseAlgorithm", "BaseIndexer", "BaseSearcher",
     "CompositeAlgorithm", "IndexArtifact", "get_algorithm_instance", "get_indexer_class", "get_searcher_class",
     "register_algorithm", "register_indexer", "register_searcher", "HipExactSearch", "HipBruteForceIndexer",
-    "HipLinearSearcher", "FlatIndex", "merge_partials_device", "merge_packed_partials_device", "HipApproximateSearch", "HipIVFIndexer", "HipIVFSearcher",
+    "HipLinearSearcher", "rerank_candidates", "FlatIndex", "merge_partials_device", "merge_packed_partials_device", "HipApproximateSearch", "HipIVFIndexer", "HipIVFSearcher",
     "IVFFlatIndex", "HipShardedExactSearch", "shard_bounds",
 ]

@@ -54,6 +54,8 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "vdb_merge_packed_partials_device": (c_int, [c_int, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p,
                                                  c_void_p]),
+    "vdb_rerank": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vdb_rerank_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vdb_ivf_train": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_uint64, c_int]),
     "vdb_ivf_set_centroids": (c_int, [c_void_p, c_void_p, c_int]),
     "vdb_ivf_get_centroids": (c_int, [c_void_p, c_void_p]),

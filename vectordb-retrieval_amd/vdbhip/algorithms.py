@@ -155,6 +155,18 @@ class HipLinearSearcher(BaseSearcher):
         return self._index.stats()["bytes_resident"] / (1024.0 * 1024.0) if getattr(self, "_index", None) else 0.0
 
 
+def rerank_candidates(index: FlatIndex, queries: np.ndarray, candidate_ids: np.ndarray, k: int, metric: str):
+    """Candidate re-scoring with the conventions of FaissSearcher._batch_search_lsh_rerank (modular.py:455-534):
+    per query the valid (>= 0) candidate ids are re-scored exactly and the best k returned -- Euclidean distance
+    for 'l2', negated score for 'cosine' / 'ip' (queries and the indexed vectors already normalised for cosine),
+    unused slots padded with +inf / -1.  One batched launch replaces the reference's per-query Python loop."""
+    d, i = index.rerank(queries, candidate_ids, k)
+    pad = i < 0
+    d = np.sqrt(np.where(pad, np.float32(0), d), dtype=np.float32) if metric == "l2" else -d
+    d[pad] = np.inf
+    return d.astype(np.float32, copy=False), i
+
+
 register_algorithm("HipExactSearch", HipExactSearch)
 register_indexer("HipBruteForceIndexer", HipBruteForceIndexer)
 register_searcher("HipLinearSearcher", HipLinearSearcher)

@@ -80,6 +80,20 @@ class FlatIndex:
         _ffi.check(self._lib.vdb_search_partial_device(self._handle(), q_ptr, int(nq), int(k), keys_ptr, ids_ptr,
                                                        stream or None))
 
+    def rerank(self, queries: np.ndarray, candidate_ids: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Exact top-k among explicit candidate ids per query (nq, ncand) int64, -1 = empty slot."""
+        q = _ffi.as_f32_c(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        c = np.ascontiguousarray(candidate_ids, dtype=np.int64)
+        if c.ndim != 2 or c.shape[0] != q.shape[0] or q.shape[1] != self.dim:
+            raise RuntimeError(f"expected queries (nq, {self.dim}) and candidates (nq, ncand), got {q.shape}, {c.shape}")
+        D = np.empty((q.shape[0], k), np.float32)
+        I = np.empty((q.shape[0], k), np.int64)
+        _ffi.check(self._lib.vdb_rerank(self._handle(), _ffi.ptr(q), q.shape[0], _ffi.ptr(c), c.shape[1], int(k),
+                                        _ffi.ptr(D), _ffi.ptr(I)))
+        return D, I
+
     # -- introspection --------------------------------------------------------------------------------
     def stats(self) -> dict:
         s = _ffi.Stats()
