@@ -65,11 +65,12 @@ typedef struct vdb_stats_s {
     int32_t last_path;         /* enum vdb_path */
     int32_t corpus_fp16_exact; /* 1 if every corpus value is exactly representable in the fp16 scan copy */
     int64_t last_nq;
-    int64_t last_candidates;   /* rows re-scored exactly by the refine kernel in the last search */
+    int64_t last_candidates;   /* candidate quads (4 consecutive rows each) re-scored exactly in the last search */
     int64_t last_rescan_bins;  /* 256-row bins re-scanned exactly (collision guard) */
     int64_t last_fallback_queries; /* queries whose work list overflowed -> exhaustive exact scan */
-    float last_scan_ms;        /* HIP-event time of the dominant (scan) kernel, last search; 0 if not timed */
-    float last_total_ms;       /* HIP-event time of the whole device pipeline, last search; 0 if not timed */
+    float last_scan_ms;        /* mean HIP-event time of the dominant (scan) kernel over the searches recorded since
+                                  timing was switched on; 0 if not timed */
+    float last_total_ms;       /* same for the whole device pipeline */
     int32_t nlist;             /* IVF: number of inverted lists (0 = flat index) */
     int32_t nprobe;
 } vdb_stats_t;
@@ -141,8 +142,9 @@ int vdb_ivf_search_device(vdb_handle h, const float *q_dev, int64_t nq, int k, f
 
 /* ---- introspection / tuning ---------------------------------------------------------------- */
 int vdb_stats(vdb_handle h, vdb_stats_t *out);
-/* options: "force_path" (0 auto, 1 exact scan only, 2 MFMA scan when legal), "timing" (0/1: record
- * HIP-event times into vdb_stats_t), "list_cap" (work-list capacity per query). */
+/* options: "force_path" (0 auto, 1 exact kernels only, 2 MFMA scan whenever legal), "timing" (1: (re)start
+ * recording HIP-event times of every search, averaged by vdb_stats), "list_cap" (work-list capacity per query),
+ * tuning knobs used by scripts/: "scan_variant", "select_variant", "spans_per_chunk". */
 int vdb_set_option(vdb_handle h, const char *key, double value);
 
 /* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */

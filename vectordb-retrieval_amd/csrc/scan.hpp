@@ -141,7 +141,7 @@ __device__ __forceinline__ void read_phase(const half8 *__restrict__ A_tile, con
 // so the per-stage barrier keeps the stagger locked.
 // BT: tiles per level-1 bin per lane half (16 -> 256-row bins for the flat index, 4 -> 64-row bins for IVF,
 // whose per-query row count is small); ITEMS: IVF work-item mode (see ScanArgs).
-template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0, int BT = 16, bool ITEMS = false>
+template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0, int BT = 16, bool ITEMS = false, int PRIO = 0>
 __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KSTEPS * 64;           // 16-byte vectors per stage
@@ -284,6 +284,10 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
 
     half8 fr[KSTEPS];
     float16v cin, acc0, acc1;
+    // static issue priority for one half of the SIMD partners keeps the phase stagger from collapsing into
+    // lockstep (equal-priority waves share the matrix pipe evenly, finish together and then both sit on the VALU)
+    if (PRIO == 1 && late) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
 
     if (!late) {
         // ================= early half: MFMA(t), then select(t) =======================================

@@ -254,7 +254,7 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
 // production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
 // ablations of variant 0 and return wrong results).
 struct ScanVariant { int nwaves, st, wps; };
-constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {8, 2, 2}, {4, 4, 2}, {4, 2, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2},
+constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {8, 2, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2},
                                          {8, 4, 2}, {8, 4, 2}, {8, 4, 2}};
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
@@ -265,8 +265,8 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
     switch (variant) {
         case 1: scan_kernel<KSTEPS, 8, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 2: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
-        case 3: scan_kernel<KSTEPS, 4, 2, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
+        case 2: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 3: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 7: scan_kernel<KSTEPS, 8, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 8: scan_kernel<KSTEPS, 8, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 9: scan_kernel<KSTEPS, 8, 4, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
