@@ -153,6 +153,10 @@ int vdb_set_option(vdb_handle h, const char *key, double value);
 int vdb_debug_scan_scores(vdb_handle h, const float *q_host, int64_t nq, int64_t row0, int64_t nrows,
                           float *scores_host, float *eps_host, double *cscale);
 
+/* per-wave cycle stamps {head, mfma, select, barrier, total, late, stages, 0} left by the diagnostic scan build
+ * (option scan_variant = 6; never used for results) -- scripts/stamp_scan.py */
+int vdb_debug_fetch_stamps(vdb_handle h, unsigned long long *out_host, int64_t max_words, int64_t *nwords);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ struct ScanArgs {
     const int32_t *list_pspan0;  // [nlist+1] panel spans of every list (lists are padded to whole spans)
     const int32_t *slot_query;   // [slots] query of every slot (-1 = padding)
     const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
+    unsigned long long *dbg;     // ABL == 4 (diagnostic build): per-wave cycle sums {head, mfma, select, barrier, total, late}
 };
 
 // (score & ~mask) | id  -- one v_and_or_b32 when the mask lives in a VGPR (the id is wave-uniform)
@@ -71,6 +72,16 @@ __host__ __device__ inline int quad_row_offset(unsigned packed_bits) {
 }
 constexpr unsigned kQuadIdMask = 0xFFFFFFC0u;
 constexpr int kQuadRows = 4;
+
+// in-kernel stamp for the diagnostic build (cdna guide, 'In-kernel stamps'): shader-cycle counter, with the
+// lgkmcnt(0) the s_memtime result needs inside the same statement, fenced against the scheduler
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 template <int KSTEPS, int ABL>
 __device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half8 (&b0)[KSTEPS],
@@ -103,7 +114,7 @@ __device__ __forceinline__ void select_phase(const float16v &acc0, const float16
         return;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < (ABL == 5 ? 2 : 4); ++g) {   // ABL 5: timing-only, half the select work
         const float q0 = fast_min(fast_min(acc0[4 * g], acc0[4 * g + 1], neg_inf),
                                   fast_min(acc0[4 * g + 2], acc0[4 * g + 3], neg_inf), neg_inf);
         const float v0 = pack_score(q0, idmask, id0 + g);
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const bool late = (NWAVES >= 2) && (wave >= NWAVES / 2);
+    const bool late = (PRIO == 3) || ((NWAVES >= 2) && (wave >= NWAVES / 2));
     int chunk = 0;
     int64_t q0, span0, span1, out_pitch, out_col;
     size_t bin_base = 0;                                    // first level-1 bin of this block's output
@@ -289,27 +300,35 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     if (PRIO == 1 && late) __builtin_amdgcn_s_setprio(1);
     if (PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
 
+    unsigned long long c_head = 0, c_mfma = 0, c_sel = 0, c_bar = 0, t_start = 0, ta = 0, tb = 0;
+    if (ABL == 4) t_start = stamp();
     if (!late) {
         // ================= early half: MFMA(t), then select(t) =======================================
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
+            if (ABL == 4) ta = stamp();
             if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);  // buf^1 was last read before the previous barrier
             const half8 *A = lds_a(buf);
             const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;                 // first tile of this stage inside its span
             read_phase<KSTEPS>(A, B4, fr, cin, lane);
+            if (ABL == 4) { tb = stamp(); c_head += tb - ta; ta = tb; }
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ABL == 4) { asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1)); tb = stamp(); c_mfma += tb - ta; ta = tb; }
                 if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
                 select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2));
+                if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);  // BT % ST == 0
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
             __syncthreads();
+            if (ABL == 4) { tb = stamp(); c_bar += tb - ta; }
         }
     } else {
         // ================= late half: select(t-1), then MFMA(t) =====================================
@@ -318,28 +337,40 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         acc1 = acc0;
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
+            if (ABL == 4) ta = stamp();
             if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
             const half8 *A = lds_a(buf);
             const float4 *B4 = reinterpret_cast<const float4 *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
+            if (ABL == 4) { tb = stamp(); c_head += tb - ta; ta = tb; }
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
-                __builtin_amdgcn_sched_barrier(0);
+                if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
                 // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
                 select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2));
                 if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
                     flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
-                __builtin_amdgcn_sched_barrier(0);
+                if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
+                if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);
+                if (ABL == 4) { asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1)); tb = stamp(); c_mfma += tb - ta; ta = tb; }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
             __syncthreads();
+            if (ABL == 4) { tb = stamp(); c_bar += tb - ta; }
         }
         select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2));  // drain the last tile
         flush_bin(span1 - 1, BPS - 1);
+    }
+    if (ABL == 4 && a.dbg && lane == 0) {
+        const unsigned long long t_end = stamp();
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+        d[0] = c_head; d[1] = c_mfma; d[2] = c_sel; d[3] = c_bar; d[4] = t_end - t_start; d[5] = late ? 1 : 0;
+        d[6] = (unsigned long long)nstages;
     }
     if (ITEMS) return;
 

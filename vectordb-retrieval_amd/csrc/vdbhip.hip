@@ -98,6 +98,7 @@ struct vdb_index_s {
     DevBuf ivf_offsets, ivf_ids, ivf_probe_d, ivf_probe_i;
     // list-major MFMA scan (D <= 128): panel space = lists padded to whole 512-row spans
     bool ivf_mfma_ok = false, ivf_last_mfma = false;
+    size_t dbg_words = 0;                    // scan_variant 6: words of per-wave stamps left in ws.dense
     int64_t ivf_pspans = 0;
     int ivf_max_pspans = 0;
     DevBuf ivf_list_pspan0, ivf_span_row0, ivf_span_valid;
@@ -254,7 +255,7 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
 // production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
 // ablations of variant 0 and return wrong results).
 struct ScanVariant { int nwaves, st, wps; };
-constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {8, 2, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2},
+constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {4, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {4, 4, 2}, {8, 4, 2},
                                          {8, 4, 2}, {8, 4, 2}, {8, 4, 2}};
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
@@ -264,9 +265,12 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
     const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
     switch (variant) {
-        case 1: scan_kernel<KSTEPS, 8, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 1: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
+        case 4: scan_kernel<KSTEPS, 8, 4, 2, 5><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 5: scan_kernel<KSTEPS, 4, 4, 2, 0, 16, false, 3><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
         case 2: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 3: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+        case 6: scan_kernel<KSTEPS, 8, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 7: scan_kernel<KSTEPS, 8, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 8: scan_kernel<KSTEPS, 8, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 9: scan_kernel<KSTEPS, 8, 4, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
@@ -534,6 +538,13 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     sa.chunk_rem = g.rem;
     sa.nchunks = g.nchunks;
     sa.Qpad = Qpad;
+    if (h->scan_variant == 6) {   // diagnostic build: per-wave cycle sums
+        const size_t nblocks = 8 * (size_t)((g.nchunks + 7) / 8) * (size_t)(Qpad / 512);
+        ws.dense.reserve(nblocks * 8 * 8 * sizeof(unsigned long long));
+        VDB_HIP(hipMemsetAsync(ws.dense.p, 0, nblocks * 8 * 8 * sizeof(unsigned long long), st));
+        sa.dbg = ws.dense.as<unsigned long long>();
+        h->dbg_words = nblocks * 8 * 8;
+    }
     timing_mark(h, tslot, 0, st);
     launch_scan(h, sa, g.nchunks, Qpad, st);
     timing_mark(h, tslot, 1, st);
@@ -978,6 +989,20 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
             s.last_total_ms = (float)(total / h->ev_used);
         }
         *out = s;
+    });
+}
+
+int vdb_debug_fetch_stamps(vdb_handle hh, unsigned long long *out_host, int64_t max_words, int64_t *nwords) {
+    return guarded([&] {
+        auto *h = check(hh);
+        if (!out_host || !nwords) throw Error(VDB_ERR_INVALID, "null pointer");
+        set_device(h->device);
+        const int64_t n = std::min<int64_t>((int64_t)h->dbg_words, max_words);
+        *nwords = n;
+        if (n > 0) {
+            VDB_HIP(hipDeviceSynchronize());
+            VDB_HIP(hipMemcpy(out_host, h->ws.dense.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        }
     });
 }
 
