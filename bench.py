@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QPS of the exact k-NN hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|gaussian1m|glove1.2m|smoke]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|gaussian1m|glove1.2m|marco2m|marco12.5m|smoke]
 
 A "step" is one pass of the hot path over one 10 000-query batch already resident in HBM:
 libvdbhip's device pipeline (query prep -> fp16 MFMA scan + bin select -> exact float64 refine), and for
@@ -43,14 +43,58 @@ WORKLOADS = {
     "gaussian1m": (1_000_000, 128, 10_000, 10, "l2", "gaussian"),
     "glove1.2m": (1_200_000, 50, 10_000, 10, "ip", "glove_like"),
     "marco2m": (2_000_000, 768, 10_000, 10, "ip", "gaussian"),   # MS MARCO-shaped shard slice (config 5 is 12.5M/GPU)
+    # BASELINE configs[4] per-GPU shard (100M x 768 over 8 GPUs): rows generated ON DEVICE in fixed 500k-row
+    # blocks seeded by the global block number, so the data do not depend on the number of ranks
+    "marco12.5m": (12_500_000, 768, 10_000, 10, "ip", "device_gaussian"),
     "smoke": (10_000, 128, 100, 10, "l2", "random_reference"),
 }
+DEVICE_BLOCK_ROWS = 500_000
+
+
+def device_rows(n: int, d: int, rank: int, dev):
+    """(n, d) float32 standard-normal rows generated on `dev`, block b of the whole corpus from seed 1234 + b."""
+    import torch
+
+    X = torch.empty((n, d), dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    blocks_per_rank = -(-n // DEVICE_BLOCK_ROWS)
+    for b in range(blocks_per_rank):
+        lo, hi = b * DEVICE_BLOCK_ROWS, min(n, (b + 1) * DEVICE_BLOCK_ROWS)
+        gen.manual_seed(1234 + rank * blocks_per_rank + b)
+        X[lo:hi].normal_(generator=gen)
+    return X
+
+
+def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32) -> float:
+    """Recall of the first `sample` queries against a float64 torch scan of the device-resident corpus (used for
+    workloads too large to hand to the CPU oracle)."""
+    import torch
+
+    q = q_t[:sample].double()
+    best_v, best_i = None, None
+    for lo in range(0, X_t.shape[0], 1_000_000):
+        x = X_t[lo:lo + 1_000_000].double()
+        s = q @ x.T if metric == "ip" else -((q * q).sum(1, keepdim=True) - 2.0 * (q @ x.T) + (x * x).sum(1)[None, :])
+        v, i = torch.topk(s, k, dim=1)
+        i = i + lo + id_base
+        if best_v is None:
+            best_v, best_i = v, i
+        else:
+            cv, ci = torch.cat([best_v, v], 1), torch.cat([best_i, i], 1)
+            best_v, sel = torch.topk(cv, k, dim=1)
+            best_i = torch.gather(ci, 1, sel)
+    got = I_t[:sample].cpu().numpy()
+    ref = best_i.cpu().numpy()
+    return float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(ref, got)]))
 
 
 def make_data(name: str, rank: int):
     from vdbhip import datasets
 
     n, d, nq, k, metric, gen = WORKLOADS[name]
+    if gen == "device_gaussian":
+        Q = np.random.default_rng(1235).standard_normal((nq, d), dtype=np.float32)
+        return None, Q, k, metric
     if gen == "sift_like":
         X = datasets._sift_rows(np.random.default_rng(1234 + 7919 * rank), n, d)
         Q = datasets._sift_rows(np.random.default_rng(1235), nq, d)
@@ -124,11 +168,17 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     X, Q, k, metric = make_data(args.workload, rank)
-    n, d = X.shape
+    n, d = WORKLOADS[args.workload][:2]
     nq = Q.shape[0]
+    X_t = device_rows(n, d, rank, dev) if X is None else None
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     index = vdbhip.FlatIndex(d, metric, local_rank)
-    index.add(X, id_base=rank * n)
+    if X is None:
+        index.add_device(X_t.data_ptr(), n, id_base=rank * n)
+        torch.cuda.synchronize()
+    else:
+        index.add(X, id_base=rank * n)
     build_s = time.perf_counter() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -209,7 +259,9 @@ def main() -> None:
                      "hbm_resident_mb": round(st["bytes_resident"] / 2 ** 20, 1)},
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if X is None:
+        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, rank * n), 6)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         gpu_ids = I_t.cpu().numpy()
         base, recall = cpu_baseline(X, Q, k, metric, gpu_ids)
         out["cpu_baseline"] = base
