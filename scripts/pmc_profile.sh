@@ -17,4 +17,5 @@ run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INS
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+run tcc3 TCC_REQ_sum TCC_READ_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum
 ls $OUT

@@ -138,6 +138,7 @@ CASES = [
     (40000, 200, 100, 10, "l2", "gauss"),   # D > 128: K-loop MFMA scan
     (36000, 768, 80, 10, "ip", "gauss"),
     (50000, 384, 70, 5, "l2", "gauss"),
+    (40000, 160, 64, 10, "ip", "gauss"),    # 192 padded dims: odd number of 64-dim K-steps
     (40000, 128, 200, 10, "l2", "gauss"),   # MFMA scan path
     (40000, 128, 200, 10, "ip", "gauss"),
     (50000, 50, 130, 10, "ip", "glove"),

@@ -385,41 +385,52 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
 
 // ---- K-loop scan for D > 128 (e.g. 384 / 768-dim embeddings) -------------------------------------------
 // Same inputs, outputs and bin semantics as scan_kernel, but the query fragments no longer fit in registers,
-// so the contraction is tiled like a GEMM: workgroup = 8 waves = (corpus chunk) x (256-query tile); wave w owns
-// ONE 32-query column block and ALL 8 row tiles of the current half span (8 x 16 accumulator registers).
-// Per 64-dim K-step the half-span's A panels (32 KiB) arrive in LDS by DMA (double buffered) and are shared
-// by the 8 waves; each wave streams its own B fragments (4 x 1 KiB per K-step) straight from L2 into
-// registers one K-step ahead.  After the K loop the 128 scores per lane go through the same 3-op select;
-// two half-span passes complete a 256-row bin per lane half.  VALU per MFMA is ~1, so this kernel is bound by
-// the matrix pipe and the LDS fragment reads (36 KiB per 32 MFMAs per wave).
+// so the contraction is tiled like a GEMM: workgroup = 8 waves = (corpus chunk) x (256*CB-query tile); wave w
+// owns CB 32-query column blocks and HT row tiles of the current span slice: HT x CB x 16 accumulator registers
+// (HT * CB = 8).  Per 64-dim K-step the slice's A panels (HT x 4 KiB) arrive in LDS by DMA (double buffered)
+// and are shared by the 8 waves; each wave streams its own B fragments (CB x 4 x 1 KiB per K-step) straight
+// from L2 into registers one K-step ahead.  After the K loop the scores go through the same 3-op quad select;
+// 16/HT passes complete a 256-row bin per lane half.
+//   HT=8, CB=1: one ds_read_b128 (1 KiB) per MFMA -- the four SIMDs then ask the LDS for its whole 128 B/clk.
+//   HT=4, CB=2: every A fragment feeds two MFMAs (LDS traffic halved); B is re-read every 128 rows instead of
+//               every 256, which is why the block order below keeps few query tiles live per XCD (B stays in L2).
+// Block order (QG = query tiles per group): within an XCD consecutive blocks walk (query group, chunk, tile in
+// group), so concurrently resident workgroups share QG B panels and each chunk stream is shared by QG blocks.
 struct ScanKloopExtra {
     int ksteps;  // 16-dim k-steps, multiple of 4
+    int qgroup;  // query tiles per group (>= 1)
 };
 
-template <int ABL = 0>
+// BS: K-steps between workgroup barriers.  The LDS holds a ring of 2*BS stages; K-step s+BS is requested during
+// K-step s into the slot that K-step s-BS used, which every wave left before the barrier that closed its group.
+template <int ABL, int HT, int CB, int BS, bool SB = true>
 __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
-    constexpr int NWAVES = 8, HT = 8;                       // waves, tiles per half span
-    constexpr int kStageVec = HT * 4 * 64;                  // 16-byte vectors per K-step stage (32 KiB)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStageVec * 16];
+    constexpr int NWAVES = 8, RING = 2 * BS;
+    constexpr int PPS = kTilesPerSpan / HT;                 // passes per span
+    constexpr int kStageVec = HT * 4 * 64;                  // 16-byte vectors per K-step stage
+    static_assert(HT * CB == 8 && (HT * 4) % NWAVES == 0, "bad blocking");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * kStageVec * 16];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
 
     const int b = blockIdx.x;
     const int x = b & 7, j = b >> 3;
-    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+    const int cpx = (a.nchunks + 7) >> 3;                   // chunks per XCD label
+    const int per_group = cpx * ex.qgroup;
+    const int qg = j / per_group, rem = j - qg * per_group;
+    const int ci = rem / ex.qgroup, qt = qg * ex.qgroup + (rem - ci * ex.qgroup);
     const int chunk = x + 8 * ci;
-    if (chunk >= a.nchunks) return;
+    if (chunk >= a.nchunks || qt >= a.nqtiles) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int KS = ex.ksteps, nK = KS / 4;
-    const int64_t q0 = (int64_t)qt * (NWAVES * 32) + wave * 32;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 32 * CB) + wave * (32 * CB);
     const float cs = a.info->cs;
-    const half8 *qp = a.qpanels + (size_t)(q0 / 32) * KS * 64 + lane;   // this wave's B panel
 
     const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
     int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
-    const int npass = (int)(span1 - span0) * 2;
+    const int npass = (int)(span1 - span0) * PPS;
     const int nsteps = npass * nK;                          // K-steps over the whole chunk
 
     const float INF = __builtin_inff();
@@ -427,98 +438,153 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
     asm volatile("" : "+v"(NEG_INF));
     unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));
-    float m1 = INF, m2 = INF, M1 = INF, M2 = INF;
-    int Ms = 0;
+    float m1[CB], m2[CB], M1[CB], M2[CB];
+    int Ms[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        m1[cb] = m2[cb] = M1[cb] = M2[cb] = INF;
+        Ms[cb] = 0;
+    }
 
+    // Global requests go through buffer descriptors: uniform 64-bit base in SGPRs + one 32-bit lane offset, so
+    // the inner loop carries no per-lane 64-bit addresses (they cost ~30 VGPRs and pushed hipcc into scratch).
+    const int lane16 = lane * 16;
     auto stage_issue = [&](int step, int buf) {             // A panels of K-step `step` -> LDS buffer
         const int pass = step / nK, kk = step - pass * nK;
-        const int64_t tile0 = (span0 + (pass >> 1)) * kTilesPerSpan + (pass & 1) * HT;
+        const int64_t tile0 = (span0 + pass / PPS) * kTilesPerSpan + (pass % PPS) * HT;
+        // ABL 3 (timing only): every request falls on the same few KiB, i.e. no L2 / fabric traffic to speak of
+        const half8 *base = ABL == 3 ? a.panels : a.panels + ((size_t)tile0 * KS + kk * 4) * 64;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(base), 0, 0x7fffffff, 0x00020000);
         half8 *dst = lds_a(buf);
 #pragma unroll
         for (int i = 0; i < (HT * 4) / NWAVES; ++i) {
             const int p = wave + i * NWAVES;                // piece = (tile t, k-step ks)
             const int t = p >> 2, ks = p & 3;
-            const half8 *g = a.panels + ((size_t)(tile0 + t) * KS + (kk * 4 + ks)) * 64 + lane;
-            __builtin_amdgcn_global_load_lds(
-                reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
-                reinterpret_cast<__attribute__((address_space(3))) void *>(
-                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
-                16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, lane16, ABL == 3 ? p * 1024 : (t * KS + ks) * 1024, 0, 0);
         }
     };
 
-    float16v acc[HT];
-    half8 bcur[4], bnext[4];
-    stage_issue(0, 0);
+    float16v acc[HT][CB];
+    // B fragments of the current K-step, reloaded in place: k-steps 0,1 of the NEXT K-step as soon as this one
+    // has used them, k-steps 2,3 at the top of their own K-step (16 / 24 MFMAs ahead of their first use), so no
+    // second register set is needed and nothing freshly requested is in flight at the barrier's vmcnt(0)
+    half8 bq[CB][4];
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half8 *>(a.qpanels + (size_t)(q0 / 32) * KS * 64), 0, 0x7fffffff, 0x00020000);
+    auto load_b = [&](int kk, int ks) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bnext[ks] = qp[(size_t)ks * 64];
+        for (int cb = 0; cb < CB; ++cb)
+            bq[cb][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rsq, lane16, (cb * KS + (ABL == 3 ? 0 : kk * 4) + ks) * 1024, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+        if (i < nsteps) stage_issue(i, i);
+    load_b(0, 0);
+    load_b(0, 1);
     __syncthreads();
+
+    // A fragments are software pipelined one k-step (HT ds_read_b128, HT*CB MFMAs) ahead in two register sets,
+    // with sched_barrier(0) pinning "request the next group, then issue this group's MFMAs" -- left to itself
+    // hipcc requests a fragment two MFMAs before its use and every group then waits out the LDS round trip.
+    half8 fr[2][HT];
+    auto read_group = [&](int buf, int ks, half8(&dst)[HT]) {
+        const half8 *A = lds_a(buf);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) dst[t] = A[(t * 4 + ks) * 64 + lane];
+    };
+    read_group(0, 0, fr[0]);
 
     int step = 0;
     for (int pass = 0; pass < npass; ++pass) {
-        const int64_t span = span0 + (pass >> 1);
-        const int half = pass & 1;
-        // accumulators start from the bias of their rows: row = 512*span + 256*h + 16*(8*half + t) + r
+        const int64_t span = span0 + pass / PPS;
+        const int slice = pass % PPS;
+        // accumulators start from the bias of their rows: row = 512*span + 256*h + 16*(HT*slice + t) + r
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             const float4 *bp = reinterpret_cast<const float4 *>(a.bias + span * kSpanRows + h * kBinRows +
-                                                                (half * HT + t) * 16);
+                                                                (slice * HT + t) * 16);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 c = bp[g];
-                acc[t][4 * g + 0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
-                acc[t][4 * g + 1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
-                acc[t][4 * g + 2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
-                acc[t][4 * g + 3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
+                acc[t][0][4 * g + 0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
+                acc[t][0][4 * g + 1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
+                acc[t][0][4 * g + 2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
+                acc[t][0][4 * g + 3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
             }
+#pragma unroll
+            for (int cb = 1; cb < CB; ++cb) acc[t][cb] = acc[t][0];
         }
+#pragma unroll 1   // (unrolled, hipcc hoists the next K-step's loads across the body and spills ~80 VGPRs)
         for (int kk = 0; kk < nK; ++kk, ++step) {
-            const int buf = step & 1;
+            const int buf = step % RING;
+            load_b(kk, 2);
+            load_b(kk, 3);
+            // (past the end of the chunk the last stage is simply requested again into a slot nobody reads, the
+            //  stale fragments read below are never used: the inner loop stays free of data-dependent branches)
+            stage_issue(step + BS < nsteps ? step + BS : nsteps - 1, (step + BS) % RING);
+            const int kn = (kk + 1 == nK) ? 0 : kk + 1;      // B repeats every pass
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
-            if (step + 1 < nsteps) {
-                stage_issue(step + 1, buf ^ 1);
-                const int kn = (kk + 1 == nK) ? 0 : kk + 1;  // B repeats every pass
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) bnext[ks] = qp[(size_t)(kn * 4 + ks) * 64];
-            }
-            const half8 *A = lds_a(buf);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    const half8 af = A[(t * 4 + ks) * 64 + lane];
-                    if (ABL != 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bcur[ks], acc[t], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (SB) __builtin_amdgcn_sched_barrier(0);
+                if (ks < 3) {
+                    read_group(buf, ks + 1, fr[(ks + 1) & 1]);
+                } else {
+                    // the barrier that publishes the next group of stages (vmcnt(0) drained by hipcc) and frees
+                    // the group just read sits in front of this K-step's last 2*HT MFMAs, so that a wave leaves
+                    // it with matrix work in hand while its first fragments of the next K-step are in flight
+                    if (BS == 1 || (step % BS) == BS - 1) __syncthreads();
+                    read_group((step + 1) % RING, 0, fr[0]);
                 }
-            __syncthreads();  // next stage landed (vmcnt(0) drained by hipcc) and this buffer is free again
+                if (SB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        if (ABL != 2)
+                            acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks & 1][t], bq[cb][ks], acc[t][cb], 0, 0, 0);
+                if (SB) __builtin_amdgcn_sched_barrier(0);
+                if (ks < 2) load_b(kn, ks);
+            }
         }
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-            const unsigned id0 = (unsigned)((half * HT + t) * 4);
+            const unsigned id0 = (unsigned)((slice * HT + t) * 4);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {       // quad minima, as in select_phase
-                const float qm = fast_min(fast_min(acc[t][4 * g], acc[t][4 * g + 1], NEG_INF),
-                                          fast_min(acc[t][4 * g + 2], acc[t][4 * g + 3], NEG_INF), NEG_INF);
-                const float v = pack_score(qm, idmask, id0 + g);
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
-                m1 = fast_min(m1, v, NEG_INF);
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {       // quad minima, as in select_phase
+                    const float qm = fast_min(fast_min(acc[t][cb][4 * g], acc[t][cb][4 * g + 1], NEG_INF),
+                                              fast_min(acc[t][cb][4 * g + 2], acc[t][cb][4 * g + 3], NEG_INF), NEG_INF);
+                    const float v = pack_score(qm, idmask, id0 + g);
+                    m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
+                    m1[cb] = fast_min(m1[cb], v, NEG_INF);
+                }
+        }
+        if (slice == PPS - 1) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + cb * 32 + (lane & 31);
+                a.bin_m1[o] = m1[cb];
+                a.bin_m2[o] = m2[cb];
+                M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+                M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+                m1[cb] = INF;
+                m2[cb] = INF;
             }
         }
-        if (half == 1) {
-            const size_t o = (size_t)(span * 2 + h) * a.Qpad + q0 + (lane & 31);
-            a.bin_m1[o] = m1;
-            a.bin_m2[o] = m2;
-            M2 = __builtin_fminf(__builtin_amdgcn_fmed3f(M1, M2, m1), m2);
-            if (m1 < M1) Ms = (int)span;
-            M1 = __builtin_fminf(M1, m1);
-            m1 = INF;
-            m2 = INF;
-        }
     }
-    const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
-    a.sb_m1[so] = M1;
-    a.sb_m2[so] = M2;
-    a.sb_span[so] = Ms;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + cb * 32 + (lane & 31);
+        a.sb_m1[so] = M1[cb];
+        a.sb_m2[so] = M2[cb];
+        a.sb_span[so] = Ms[cb];
+    }
 }
 
 // ---- select: per query, turn the bin minima into an exact-refine work list --------------------------

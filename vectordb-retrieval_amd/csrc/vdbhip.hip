@@ -80,7 +80,7 @@ struct vdb_index_s {
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
     // options
-    int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0;
+    int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     // per-search
     Workspace ws;
     vdb_stats_t last{};
@@ -280,9 +280,23 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
 
 void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
     if (h->ksteps > kMaxKSteps) {  // D > 128
-        sa.nqtiles = (int)(Qpad / 256);
-        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
-        scan_kloop_kernel<0><<<dim3(grid), dim3(512), 0, st>>>(sa, ScanKloopExtra{h->ksteps});
+        // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
+        // option kloop_qgroup = query tiles per group of the block order (0 -> default)
+        const bool wide = h->scan_variant != 1;
+        sa.nqtiles = (int)(Qpad / (wide ? 512 : 256));
+        int qgroup = h->kloop_qgroup > 0 ? h->kloop_qgroup : (wide ? 4 : sa.nqtiles);
+        qgroup = std::min(qgroup, sa.nqtiles);
+        const unsigned ngroups = (unsigned)((sa.nqtiles + qgroup - 1) / qgroup);
+        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * ngroups * (unsigned)qgroup;
+        const ScanKloopExtra ex{h->ksteps, qgroup};
+        switch (h->scan_variant) {
+            case 1: scan_kloop_kernel<0, 8, 1, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+            case 2: scan_kloop_kernel<0, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+            case 3: scan_kloop_kernel<0, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+            case 7: scan_kloop_kernel<2, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
+            case 8: scan_kloop_kernel<3, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
+            default: scan_kloop_kernel<0, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+        }
     } else if (h->ksteps == 4)
         launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st);
     else
@@ -1017,6 +1031,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "timing") {  // (re)starts the recording window
             h->timing = value != 0;
             h->ev_used = 0;
+        } else if (k == "kloop_qgroup") {
+            if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
+            h->kloop_qgroup = (int)value;
         } else if (k == "scan_variant") {
             if (value < 0 || value >= kNumScanVariants) throw Error(VDB_ERR_INVALID, "scan_variant out of range");
             h->scan_variant = (int)value;
