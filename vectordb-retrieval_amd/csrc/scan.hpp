@@ -403,9 +403,11 @@ struct ScanKloopExtra {
 
 // BS: K-steps between workgroup barriers.  The LDS holds a ring of 2*BS stages; K-step s+BS is requested during
 // K-step s into the slot that K-step s-BS used, which every wave left before the barrier that closed its group.
-template <int ABL, int HT, int CB, int BS, bool SB = true>
-__global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
-    constexpr int NWAVES = 8, RING = 2 * BS;
+// NW: waves per workgroup (8: one workgroup per CU; 4: two independent workgroups per CU, each with its own barrier).
+// ABL: timing-only builds -- 2 no MFMA, 3 no L2 traffic, 4 no pass epilogue / bias init.
+template <int ABL, int HT, int CB, int BS, bool SB = true, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void scan_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
+    constexpr int NWAVES = NW, RING = 2 * BS;
     constexpr int PPS = kTilesPerSpan / HT;                 // passes per span
     constexpr int kStageVec = HT * 4 * 64;                  // 16-byte vectors per K-step stage
     static_assert(HT * CB == 8 && (HT * 4) % NWAVES == 0, "bad blocking");
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
         const int slice = pass % PPS;
         // accumulators start from the bias of their rows: row = 512*span + 256*h + 16*(HT*slice + t) + r
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
+        for (int t = 0; t < (ABL == 4 ? 0 : HT); ++t) {
             const float4 *bp = reinterpret_cast<const float4 *>(a.bias + span * kSpanRows + h * kBinRows +
                                                                 (slice * HT + t) * 16);
 #pragma unroll
@@ -550,8 +552,14 @@ __global__ __launch_bounds__(512, 2) void scan_kloop_kernel(ScanArgs a, ScanKloo
                 if (ks < 2) load_b(kn, ks);
             }
         }
+        if (ABL == 4) {      // keep the accumulators alive with one cheap use
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) m1[cb] = fast_min(m1[cb], acc[t][cb][0], NEG_INF);
+        }
+#pragma unroll
+        for (int t = 0; t < (ABL == 4 ? 0 : HT); ++t) {
             const unsigned id0 = (unsigned)((slice * HT + t) * 4);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)

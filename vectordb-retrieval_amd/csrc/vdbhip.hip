@@ -282,7 +282,7 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
     if (h->ksteps > kMaxKSteps) {  // D > 128
         // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
         // option kloop_qgroup = query tiles per group of the block order (0 -> default)
-        const bool wide = h->scan_variant != 1;
+        const bool wide = h->scan_variant != 1 && h->scan_variant != 4;   // 512-query tiles
         sa.nqtiles = (int)(Qpad / (wide ? 512 : 256));
         int qgroup = h->kloop_qgroup > 0 ? h->kloop_qgroup : (wide ? 4 : sa.nqtiles);
         qgroup = std::min(qgroup, sa.nqtiles);
@@ -293,6 +293,8 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
             case 1: scan_kloop_kernel<0, 8, 1, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             case 2: scan_kloop_kernel<0, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             case 3: scan_kloop_kernel<0, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+            case 4: scan_kloop_kernel<0, 4, 2, 1, true, 4><<<dim3(grid), dim3(256), 0, st>>>(sa, ex); break;
+            case 9: scan_kloop_kernel<4, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
             case 7: scan_kloop_kernel<2, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
             case 8: scan_kloop_kernel<3, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
             default: scan_kloop_kernel<0, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
