@@ -139,6 +139,10 @@ int vdb_ivf_get_assignment(vdb_handle h, int32_t *list_of_row_host);
 int vdb_ivf_search(vdb_handle h, const float *q_host, int64_t nq, int k, float *D, int64_t *I);
 int vdb_ivf_search_device(vdb_handle h, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
                           void *stream);
+/* row-sharded IVF (coarse quantizer replicated, the rows of every list split over the ranks): per-shard
+ * partial top-k among the probed lists, same layout and merge as vdb_search_partial_device */
+int vdb_ivf_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, int k, double *keys_dev,
+                                  int64_t *ids_dev, void *stream);
 
 /* ---- introspection / tuning ---------------------------------------------------------------- */
 int vdb_stats(vdb_handle h, vdb_stats_t *out);

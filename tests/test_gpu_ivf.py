@@ -222,3 +222,47 @@ def test_ivf_persistence_round_trip(vdb, tmp_path):
     # algorithms without persistence keep the base-class behaviour
     with pytest.raises(NotImplementedError):
         vdb.HipExactSearch("e", 4).save_index(str(tmp_path / "x"))
+
+
+@pytest.mark.parametrize("metric,nshards", [("l2", 2), ("ip", 3)])
+def test_row_sharded_ivf_partials_merge_to_unsharded_result(vdb, oracle, metric, nshards):
+    """SURVEY 8e for IVF: shared centroids, the rows of every list split over shards, per-shard partial top-k
+    (vdb_ivf_search_partial_device) merged by (float64 key, id) == the unsharded index, bit for bit.  Covers the
+    list-major MFMA scan (300 queries) and the exact list scan (20 queries) on the shards."""
+    import torch
+
+    n, d, nlist, k = 60000, 64, 128, 10
+    X, Q = _data(n, d, 300, seed=99)
+    C = X[np.random.default_rng(5).choice(n, nlist, replace=False)].copy()
+    full = vdb.IVFFlatIndex(d, nlist, metric, 0)
+    full.set_centroids(C)
+    full.add(X, id_base=7)
+    shards = []
+    for r in range(nshards):
+        lo, hi = vdb.sharded.shard_bounds(n, nshards, r)
+        s = vdb.IVFFlatIndex(d, nlist, metric, 0)
+        s.set_centroids(C)
+        s.add(X[lo:hi], id_base=7 + lo)
+        shards.append(s)
+    dev = torch.device("cuda:0")
+    for nq, nprobe in ((300, 8), (20, 8), (300, 1), (64, nlist)):
+        q_t = torch.from_numpy(Q[:nq]).to(dev)
+        full.set_nprobe(nprobe)
+        D_ref, I_ref = full.search(Q[:nq], k)
+        pack = torch.empty((nshards, 2, nq, k), dtype=torch.int64, device=dev)
+        for r, s in enumerate(shards):
+            s.set_nprobe(nprobe)
+            s.search_partial_device(q_t.data_ptr(), nq, k, pack[r, 0].data_ptr(), pack[r, 1].data_ptr())
+        D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        vdb.merge_packed_partials_device(metric, 0, pack.data_ptr(), nshards, nq, k, D_t.data_ptr(), I_t.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(I_t.cpu().numpy(), I_ref)
+        np.testing.assert_array_equal(D_t.cpu().numpy(), D_ref)
+        # partial keys are sorted ascending with (+inf, -1) padding
+        keys = pack[:, 0].cpu().numpy().view(np.float64)
+        assert np.all(np.diff(keys, axis=-1) >= 0)
+    Do, Io = oracle.ivf_search(X, C, full.assignment(), Q[:64], k, nlist, metric, id_base=7)
+    np.testing.assert_array_equal(I_ref, Io)
+    for s in shards + [full]:
+        s.close()

@@ -167,3 +167,38 @@ def test_fvecs_ivecs_readers(tmp_path):
     m = io.open_npy_rows(tmp_path / "c.npy", limit=20)
     assert isinstance(m, np.memmap) or isinstance(m.base, np.memmap)
     np.testing.assert_array_equal(np.asarray(m), x[:20])
+
+
+def test_harness_warmup_and_latency_summary():
+    """warm-up batches before the timed pass, first-call time beside it, and the latency keys of
+    the reference's compute_cost_latency (metrics.py:212-237).  Host logic only: the algorithm is a stub."""
+    from vdbhip.harness import run_single_algorithm
+    from vdbhip.metrics import latency_stats
+    from vdbhip.plugin_api import BaseAlgorithm
+
+    class Stub(BaseAlgorithm):
+        calls = 0
+
+        def build_index(self, vectors, metadata=None):
+            self.vectors, self.index_built = vectors, True
+
+        def search(self, query, k=10):
+            return np.zeros(k, np.float32), np.arange(k, dtype=np.int64)
+
+        def batch_search(self, queries, k=10):
+            Stub.calls += 1
+            self.record_operation("ndis", float(len(queries)) * len(self.vectors))
+            return np.zeros((len(queries), k), np.float32), np.tile(np.arange(k, dtype=np.int64), (len(queries), 1))
+
+    train = np.zeros((50, 4), np.float32)
+    test = np.zeros((12, 4), np.float32)
+    gt = np.tile(np.arange(10, dtype=np.int32), (12, 1))
+    out = run_single_algorithm(Stub("stub", 4), train, test, gt, topk=10, query_batch_size=5, warmup_batches=3)["metrics"]
+    assert Stub.calls == 3 + 3                       # 3 warm-up replays of the first batch + ceil(12/5) timed batches
+    assert out["warmup_batches"] == 3 and out["first_call_s"] >= 0.0
+    assert set(out["latency_s"]) == {"mean", "median", "p95", "p99", "min", "max"}
+    assert out["recall@10"] == 1.0 and out["used_batch_api"]
+    assert out["operations_per_query"] == pytest.approx(50.0)      # warm-up work is not counted
+    s = latency_stats([1.0, 2.0, 3.0, 4.0])
+    assert s["mean"] == 2.5 and s["median"] == 2.5 and s["min"] == 1.0 and s["max"] == 4.0
+    assert s["p95"] == pytest.approx(np.percentile([1, 2, 3, 4], 95))

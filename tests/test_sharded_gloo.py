@@ -56,6 +56,79 @@ class _OracleEngine:
                                      self.metric)
 
 
+class _OracleIVFEngine(_OracleEngine):
+    """CPU stand-in for HipIVFShardEngine: k-means is replaced by a seeded row sample (the plumbing under test is
+    train-on-rank-0 + broadcast + per-shard add + partial merge, not the clustering)."""
+
+    def __init__(self, dim, metric, device, nlist):
+        super().__init__(dim, metric, device)
+        self.nlist, self.nprobe, self.trained_here = nlist, 1, False
+
+    def train(self, x, **kw):
+        self.trained_here = True
+        self.C = np.ascontiguousarray(x[np.random.default_rng(kw.get("seed", 1234)).choice(len(x), self.nlist, replace=False)])
+        return self.C
+
+    def set_centroids(self, c):
+        self.C = np.ascontiguousarray(c)
+
+    def set_nprobe(self, nprobe):
+        self.nprobe = int(nprobe)
+
+    def search_partial(self, q, k):
+        qn = q.numpy()
+        lor = self.o.ivf_assign(self.C, self.x, self.metric)
+        _, ids = self.o.ivf_search(self.x, self.C, lor, qn, k, self.nprobe, self.metric, id_base=self.id_base)
+        keys = np.full(ids.shape, np.inf)
+        for i in range(len(qn)):      # exact float64 keys of the rows found (partial contract: key +inf / id -1 padding)
+            m = ids[i] >= 0
+            if m.any():
+                keys[i, m] = self.o.pair_keys(self.x, qn[i:i + 1], (ids[i, m] - self.id_base)[None, :], self.metric)[0]
+        return self.torch.from_numpy(np.stack([keys.view(np.int64), ids]))
+
+
+def _ivf_worker(rank, world, port, out_dir):
+    sys.path[:0] = [str(ROOT), str(ROOT / "vectordb-retrieval_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from vdbhip.sharded import HipShardedApproximateSearch
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        X = rng.standard_normal((1500, 16)).astype(np.float32)
+        Q = rng.standard_normal((9, 16)).astype(np.float32)
+        for metric in ("l2", "ip"):
+            algo = HipShardedApproximateSearch("ivf_sh", 16, "IVF12,Flat", metric=metric, nprobe=3, seed=5,
+                                               engine_factory=_OracleIVFEngine)
+            algo.build_index(X)
+            d, i = algo.batch_search(Q, k=6)
+            np.savez(Path(out_dir) / f"ivf_r{rank}_{metric}.npz", d=d, i=i, C=algo.centroids,
+                     trained=np.array(algo.engine.trained_here))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_sharded_ivf_equals_unsharded(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_ivf_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((1500, 16)).astype(np.float32)
+    Q = rng.standard_normal((9, 16)).astype(np.float32)
+    for metric in ("l2", "ip"):
+        g0, g1 = (np.load(tmp_path / f"ivf_r{r}_{metric}.npz") for r in range(world))
+        assert bool(g0["trained"]) and not bool(g1["trained"])       # trained once, on rank 0 ...
+        np.testing.assert_array_equal(g0["C"], g1["C"])              # ... and broadcast
+        C = g0["C"]
+        d_ref, i_ref = oracle.ivf_search(X, C, oracle.ivf_assign(C, X, metric), Q, 6, 3, metric)
+        for g in (g0, g1):
+            np.testing.assert_array_equal(g["i"], i_ref)
+            np.testing.assert_array_equal(g["d"], d_ref)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path[:0] = [str(ROOT), str(ROOT / "vectordb-retrieval_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

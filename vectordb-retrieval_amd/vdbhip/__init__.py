@@ -9,12 +9,14 @@ from .plugin_api import (ALGORITHM_REGISTRY, INDEXER_REGISTRY, SEARCHER_REGISTRY
 from .algorithms import HipBruteForceIndexer, HipExactSearch, HipLinearSearcher, rerank_candidates
 from .index import FlatIndex, merge_packed_partials_device, merge_partials_device
 from .ivf import HipApproximateSearch, HipIVFIndexer, HipIVFSearcher, IVFFlatIndex
-from .sharded import HipShardedExactSearch, shard_bounds
+from . import sharded
+from .sharded import HipShardedApproximateSearch, HipShardedExactSearch, shard_bounds
 
 __all__ = [
     "ALGORITHM_REGISTRY", "INDEXER_REGISTRY", "SEARCHER_REGISTRY", "BaseAlgorithm", "BaseIndexer", "BaseSearcher",
     "CompositeAlgorithm", "IndexArtifact", "get_algorithm_instance", "get_indexer_class", "get_searcher_class",
     "register_algorithm", "register_indexer", "register_searcher", "HipExactSearch", "HipBruteForceIndexer",
-    "HipLinearSearcher", "rerank_candidates", "FlatIndex", "merge_partials_device", "merge_packed_partials_device", "HipApproximateSearch", "HipIVFIndexer", "HipIVFSearcher",
-    "IVFFlatIndex", "HipShardedExactSearch", "shard_bounds",
+    "HipLinearSearcher", "rerank_candidates", "FlatIndex", "merge_partials_device", "merge_packed_partials_device",
+    "HipApproximateSearch", "HipIVFIndexer", "HipIVFSearcher", "IVFFlatIndex", "HipShardedExactSearch",
+    "HipShardedApproximateSearch", "shard_bounds", "sharded",
 ]

@@ -110,6 +110,11 @@ class IVFFlatIndex:
     def search_device(self, q_ptr: int, nq: int, k: int, d_ptr: int, i_ptr: int, stream: int = 0) -> None:
         _ffi.check(self._lib.vdb_ivf_search_device(self._h, q_ptr, int(nq), int(k), d_ptr, i_ptr, stream or None))
 
+    def search_partial_device(self, q_ptr: int, nq: int, k: int, keys_ptr: int, ids_ptr: int, stream: int = 0) -> None:
+        """Per-shard partial top-k (float64 order keys + global ids) among the probed lists; device pointers."""
+        _ffi.check(self._lib.vdb_ivf_search_partial_device(self._h, q_ptr, int(nq), int(k), keys_ptr, ids_ptr,
+                                                           stream or None))
+
     def stats(self) -> dict:
         s = _ffi.Stats()
         _ffi.check(self._lib.vdb_stats(self._h, ctypes.byref(s)))

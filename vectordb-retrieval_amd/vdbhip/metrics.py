@@ -14,3 +14,13 @@ def recall_at_k(ground_truth: np.ndarray, predicted: np.ndarray, k: int) -> floa
         if truth:
             hits += len(truth.intersection(pred_row[:k].tolist())) / len(truth)
     return hits / max(len(ground_truth), 1)
+
+
+def latency_stats(timing_data) -> dict:
+    """Latency summary with the keys of the reference's (unwired) `compute_cost_latency`
+    (src/benchmark/metrics.py:212-237): mean / median / p95 / p99 / min / max of per-query seconds."""
+    t = np.asarray(list(timing_data), dtype=np.float64)
+    if t.size == 0:
+        return {k: 0.0 for k in ("mean", "median", "p95", "p99", "min", "max")}
+    return {"mean": float(t.mean()), "median": float(np.median(t)), "p95": float(np.percentile(t, 95)),
+            "p99": float(np.percentile(t, 99)), "min": float(t.min()), "max": float(t.max())}

@@ -6,6 +6,11 @@ rank scans its shard for the SAME query batch, the per-shard partial top-k (floa
 `vdb_search_partial_device`, packed into one buffer) are exchanged with ONE all-gather, and every rank merges
 them with `vdb_merge_packed_partials_device`.  The merge key (float64 key, id) makes the result independent of W.
 
+`HipShardedApproximateSearch` shards IVF-Flat the same way: the coarse quantizer is trained on rank 0
+and broadcast (the one other collective on the path), every rank files ITS rows under the shared centroids, probes
+the same lists and contributes `vdb_ivf_search_partial_device` partials to the same all-gather + merge, so the
+result equals the unsharded IVF index built on those centroids.
+
 The collective and the shard arithmetic live here; the per-shard engine is pluggable so the N > 1 plumbing is
 testable on CPU with the gloo backend (tests/test_sharded_gloo.py injects a CPU engine built on the oracle --
 the product default is the HIP engine below and there is no CPU fallback).
@@ -135,4 +140,84 @@ class HipShardedExactSearch(BaseAlgorithm):
         return d[0], i[0]
 
 
+class HipIVFShardEngine(HipShardEngine):
+    """Per-rank IVF engine: IVFFlatIndex on this rank's GPU filled with this rank's rows."""
+
+    def __init__(self, dim: int, metric: str, device: int, nlist: int):
+        import torch
+
+        from .ivf import IVFFlatIndex
+
+        self.torch = torch
+        self.metric, self.device = metric, device
+        torch.cuda.set_device(device)
+        self.dev = torch.device("cuda", device)
+        self.index = IVFFlatIndex(dim, nlist, metric, device)
+
+    def train(self, x: np.ndarray, **kw) -> np.ndarray:
+        self.index.train(x, **kw)
+        return self.index.centroids()
+
+    def set_centroids(self, c: np.ndarray) -> None:
+        self.index.set_centroids(c)
+
+    def set_nprobe(self, nprobe: int) -> None:
+        self.index.set_nprobe(nprobe)
+
+
+def broadcast_array(arr: Optional[np.ndarray], shape, world: int, src: int = 0) -> np.ndarray:
+    """float32 array of `shape` from rank `src` to every rank (centroids: nlist x dim, a few hundred KiB)."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return np.ascontiguousarray(arr, np.float32)
+    use_cuda = dist.get_backend() == "nccl"
+    t = torch.empty(shape, dtype=torch.float32) if arr is None else torch.from_numpy(np.ascontiguousarray(arr, np.float32))
+    if use_cuda:
+        t = t.cuda()
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+class HipShardedApproximateSearch(HipShardedExactSearch):
+    """ApproximateSearch semantics ("IVF<nlist>,Flat", approximate_search.py:12-87) over a row-sharded corpus."""
+
+    def __init__(self, name: str, dimension: int, index_type: str, metric: str = "l2", device: Optional[int] = None,
+                 engine_factory: Optional[Callable[..., Any]] = None, **kwargs: Any) -> None:
+        super().__init__(name, dimension, metric=metric, device=device, engine_factory=engine_factory, **kwargs)
+        from .ivf import parse_ivf_key
+
+        self.index_type = index_type
+        self.nlist = parse_ivf_key(index_type)
+
+    def build_index(self, vectors: np.ndarray, metadata: Metadata = None) -> None:
+        import os
+
+        self.rank, self.world = self._dist()
+        x = _ffi.as_f32_c(vectors)
+        if x.ndim != 2 or x.shape[1] != self.dimension:
+            raise ValueError(f"expected (n, {self.dimension}) vectors, got {x.shape}")
+        self.ntotal = int(x.shape[0])
+        lo, hi = shard_bounds(self.ntotal, self.world, self.rank)
+        device = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", self.rank))
+        factory = self._engine_factory or HipIVFShardEngine
+        self.engine = factory(self.dimension, self.metric, device, self.nlist)
+        cfg = self.config
+        centroids = None
+        if self.rank == 0:      # approximate_search.py:44: index.train(vectors) -- on the WHOLE corpus, once
+            centroids = self.engine.train(x, niter=int(cfg.get("niter", 25)), seed=int(cfg.get("seed", 1234)),
+                                          max_points_per_centroid=int(cfg.get("max_points_per_centroid", 256)))
+        centroids = broadcast_array(centroids, (self.nlist, self.dimension), self.world)
+        if self.rank != 0:
+            self.engine.set_centroids(centroids)
+        self.centroids = centroids
+        self.engine.add(x[lo:hi], lo)
+        if "nprobe" in cfg:     # approximate_search.py:50-51
+            self.engine.set_nprobe(int(cfg["nprobe"]))
+        self.shard = (lo, hi)
+        self.index_built = True
+
+
 register_algorithm("HipShardedExactSearch", HipShardedExactSearch)
+register_algorithm("HipShardedApproximateSearch", HipShardedApproximateSearch)
