@@ -248,7 +248,7 @@ def main() -> None:
                                f"brute-force exact k-NN, inputs resident in HBM",
                    "rows_per_gpu": n, "dim": d, "queries": nq, "k": k, "metric": metric,
                    "sharding": "none" if world == 1 else f"row-sharded x{world}, RCCL all-gather of partial top-k"},
-        "roofline": {"bound": "mfma", "kernel": ("scan_kernel<%d>" % (4 if d <= 64 else 8)) if d <= 128 else "scan_kloop_kernel",
+        "roofline": {"bound": "mfma", "kernel": ("scan_kernel<%d>" % (4 if d <= 64 else 8)) if d <= 128 else "scan16_kloop_kernel",
                      "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                      "kernel_ms": round(scan_ms, 4), "pipeline_ms": round(float(st["last_total_ms"]), 4),

@@ -23,6 +23,11 @@ constexpr int kTileRows = 32;
 constexpr int kSpanRows = 512;      // 16 tiles; two bins (h = 0,1) of 256 rows
 constexpr int kBinRows = 256;
 constexpr int kTilesPerSpan = 16;
+// layout "p16" (16-row tiles for v_mfma_f32_16x16x32_f16): span = 64 tiles = 1024 rows = four 256-row bins, one
+// per lane group g = lane>>4 of the 16x16 C/D layout
+constexpr int kTileRows16 = 16;
+constexpr int kSpanRows16 = 1024;
+constexpr int kTilesPerSpan16 = 64;
 constexpr int kStageTiles = 4;      // tiles per LDS stage (128 MFMA rows)
 constexpr int kMaxKSteps = 8;       // register-resident query fragments: D <= 128
 constexpr float kPadBias = 1.0e38f; // accumulator init of padding rows (scan units): never selected

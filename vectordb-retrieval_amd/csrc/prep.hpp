@@ -82,6 +82,42 @@ __global__ __launch_bounds__(256) void build_panels_kernel(const float *__restri
     if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
 }
 
+// ---- 16-row-tile panels for v_mfma_f32_16x16x32_f16 (layout "p16", see common.hpp) ------------------------
+// one thread per (tile, 32-dim k-step, lane): lane l holds A row rho = l&15, dims 32*ks + 8*(l>>4) .. +7.
+// Row mapping: span = 1024 rows = 64 tiles; tile t of span s, MFMA row rho = 4g+i  <->  corpus row
+// 1024 s + 256 g + 4 t + i, so the lane group g = l>>4 of the C/D layout (col = l&15, rows 4g..4g+3) walks 256
+// CONSECUTIVE corpus rows per span, one quad per tile.
+__global__ __launch_bounds__(256) void build_panels16_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
+                                                             int ks32, int64_t ntiles, float sx,
+                                                             half8 *__restrict__ panels, IndexStats *st) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ks32);
+    const int64_t tile = tk / ks32;
+    int inexact = 0;
+    if (tile < ntiles) {
+        const int rho = lane & 15, kq = lane >> 4;
+        const int g = rho >> 2, i = rho & 3;
+        const int64_t span = tile / kTilesPerSpan16;
+        const int t = (int)(tile - span * kTilesPerSpan16);
+        const int64_t row = span * kSpanRows16 + (int64_t)g * kBinRows + 4 * t + i;
+        const int d0 = ks * 32 + kq * 8;
+        half8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = d0 + j;
+            float v = 0.f;
+            if (row < N && d < D) v = X[(size_t)row * D4 + d] * sx;
+            const _Float16 hv = (_Float16)v;
+            inexact |= ((float)hv != v);
+            out[j] = hv;
+        }
+        panels[gid] = out;
+    }
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+}
+
 // bias (C-init of the MFMA accumulators): ||x||^2 for L2, 0 for IP, pad marker beyond N.
 __global__ __launch_bounds__(256) void build_bias_kernel(const float *__restrict__ xnorm2, int64_t N, int64_t Npad,
                                                          int metric, float *__restrict__ bias) {
@@ -153,6 +189,31 @@ __global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restr
     const float bs = info->bscale;
     const int64_t q = qt * 32 + (lane & 31);
     const int d0 = ks * 16 + (lane >> 5) * 8;
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = d0 + j;
+        float v = 0.f;
+        if (q < nq && d < D) v = Q[(size_t)q * D + d] * bs;
+        out[j] = (_Float16)v;
+    }
+    qpanels[gid] = out;
+}
+
+// B fragments for v_mfma_f32_16x16x32_f16: thread per (16-query block, 32-dim k-step, lane); lane l holds query
+// column l&15, dims 32*ks + 8*(l>>4) .. +7.
+__global__ __launch_bounds__(256) void build_qpanels16_kernel(const float *__restrict__ Q, int64_t nq, int D, int ks32,
+                                                              int64_t nqblocks, const QueryBatchInfo *__restrict__ info,
+                                                              half8 *__restrict__ qpanels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ks32);
+    const int64_t qb = tk / ks32;
+    if (qb >= nqblocks) return;
+    const float bs = info->bscale;
+    const int64_t q = qb * 16 + (lane & 15);
+    const int d0 = ks * 32 + (lane >> 4) * 8;
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -607,6 +607,7 @@ struct SelectArgs {
     const QueryBatchInfo *info;
     int64_t nq, Qpad, nspans, N;
     int spans_per_chunk, chunk_rem, nchunks, k;
+    int groups;                  // bins per span: 2 (32-row tiles, 512-row spans) or 4 (p16: 16-row tiles, 1024-row spans)
     int cand_cap, rescan_cap;
     int32_t *cand_rows;          // [nq][cand_cap]
     int32_t *rescan_rows;        // [nq][rescan_cap]
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (q >= a.nq) return;
-    const int nsb = a.nchunks * 2;
+    const int nsb = a.nchunks * a.groups;
     unsigned v[VPL];
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
@@ -665,8 +666,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             const unsigned long long smask = __ballot(single);
             if (single) {
                 const int pos = ncand + __popcll(smask & lt_mask);
-                const int hh = s & 1;
-                const int row = sspan * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(m1));
+                const int hh = s % a.groups;
+                const int row = (sspan * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(m1));
                 if (pos < a.cand_cap) cr[pos] = row;
             }
             ncand += __popcll(smask);
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                 const int src = __ffsll(dmask) - 1;
                 dmask &= dmask - 1;
                 const int sb = e * 64 + src;
-                const int chunk = sb >> 1, hh = sb & 1;
+                const int chunk = sb / a.groups, hh = sb % a.groups;
                 const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
                 int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
                 if (sp1 > a.nspans) sp1 = a.nspans;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     bool act = false, resc = false;
                     float bm1 = 0.f;
                     if (sp < sp1) {
-                        const size_t o = (size_t)(sp * 2 + hh) * a.Qpad + q;
+                        const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
                         bm1 = a.bin_m1[o];
                         if (bm1 <= that) {
                             act = true;
@@ -697,12 +698,12 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if (cand) {
                         const int pos = ncand + __popcll(cm & lt_mask);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(bm1)));
+                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
                         if (pos < a.rescan_cap) {
-                            rr[2 * pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                            rr[2 * pos] = (int)((sp * a.groups + hh) * kBinRows);
                             rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
                         }
                     }
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     const int qi = lane / LPQ, part = lane % LPQ;
     const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QPW + qi;   // < Qpad by construction of the grid
     const bool qvalid = q < a.nq;
-    const int nsb = a.nchunks * 2;
+    const int nsb = a.nchunks * a.groups;
     if (part < 2) s_cnt[wave][qi][part] = 0;
     unsigned v[V];
 #pragma unroll
@@ -783,30 +784,30 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             if (s >= nsb) continue;
             const float m1 = unsortable_f32(v[e]);
             if (!(m1 <= that)) continue;
-            const int hh = s & 1;
+            const int hh = s % a.groups;
             if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
-                    cr[pos] = spanv[e] * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(m1));
+                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(m1));
             } else {               // two or more interesting scores: walk the level-1 bins of this superbin
-                const int chunk = s >> 1;
+                const int chunk = s / a.groups;
                 const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
                 int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
                 if (sp1 > a.nspans) sp1 = a.nspans;
                 for (int64_t sp = sp0; sp < sp1; ++sp) {
-                    const size_t o = (size_t)(sp * 2 + hh) * a.Qpad + q;
+                    const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
                     const float bm1 = a.bin_m1[o];
                     if (!(bm1 <= that)) continue;
                     if (a.bin_m2[o] <= that) {
                         const int pos = atomicAdd(cnt_r, 1);
                         if (pos < a.rescan_cap) {
-                            rr[2 * pos] = (int)(sp * kSpanRows + hh * kBinRows);
+                            rr[2 * pos] = (int)((sp * a.groups + hh) * kBinRows);
                             rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
                         }
                     } else {
                         const int pos = atomicAdd(cnt_c, 1);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)(sp * kSpanRows + hh * kBinRows + quad_row_offset(__float_as_uint(bm1)));
+                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                     }
                 }
             }

@@ -1,0 +1,194 @@
+// scan16.hpp -- scan kernels on the "p16" panel layout (16-row tiles, v_mfma_f32_16x16x32_f16).
+//
+// Why a second MFMA shape: at these operand mixes the MI355X sits at its power limit, and the 16x16x32 shape
+// delivers 1.07-1.16x the FLOP/s of 32x32x16 for the same flops and the same LDS bytes per flop
+// (scripts/microbench/mfma_shape.hip).  The bin / superbin semantics and the packed quad ids are
+// those of scan.hpp: in the 16x16 C/D layout (col = lane&15, rows 4g..4g+3, g = lane>>4) a lane owns ONE query
+// column and its 4 accumulator registers are 4 consecutive corpus rows = one quad; the p16 row mapping
+// (common.hpp) makes lane group g walk the 256 consecutive rows of bin (span, g), one quad per tile, so a packed
+// minimum's 6-bit id is the tile number inside the span and bin b covers rows [256 b, 256 b + 256).
+#pragma once
+
+#include "scan.hpp"
+
+namespace vdb {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// ---- K-loop scan for D > 128 on p16 panels ---------------------------------------------------------------
+// Workgroup = 8 waves = (corpus chunk) x (512-query tile); wave w owns four 16-query column blocks and, per pass,
+// eight 16-row tiles (8 x 4 x 4 = 128 accumulator registers: a 128-row x 64-query output tile, as the 32x32 form).
+// Per 64-dim K-step (two 32-dim k-steps) the pass's A panels (16 KiB) arrive in LDS by buffer-addressed LDS-DMA
+// and are shared by the 8 waves; each wave streams its own B fragments (8 x 1 KiB per K-step) from L2 in place.
+// A fragments are software pipelined one group (4 ds_read_b128 -> 16 MFMAs) ahead; 4 groups per K-step:
+// (k-step 0, tiles 0-3), (0, 4-7), (1, 0-3), (1, 4-7).  Eight passes complete the four 256-row bins of a span.
+// BS / ring / barrier placement / ABL builds: see scan_kloop_kernel.
+template <int ABL, int BS>
+__global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
+    constexpr int NWAVES = 8, RING = 2 * BS, HT = 8, CB = 4;
+    constexpr int PPS = kTilesPerSpan16 / HT;               // passes per span (8)
+    constexpr int kStageVec = HT * 2 * 64;                  // 16-byte vectors per K-step stage (16 KiB)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * kStageVec * 16];
+    auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
+
+    const int b = blockIdx.x;
+    const int x = b & 7, j = b >> 3;
+    const int cpx = (a.nchunks + 7) >> 3;                   // chunks per XCD label
+    const int per_group = cpx * ex.qgroup;
+    const int qg = j / per_group, rem = j - qg * per_group;
+    const int ci = rem / ex.qgroup, qt = qg * ex.qgroup + (rem - ci * ex.qgroup);
+    const int chunk = x + 8 * ci;
+    if (chunk >= a.nchunks || qt >= a.nqtiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;                                // lane group = bin of the span
+    const int KS = ex.ksteps / 2, nK = KS / 2;              // 32-dim k-steps; 64-dim K-steps
+    const int64_t q0 = (int64_t)qt * (NWAVES * 16 * CB) + wave * (16 * CB);
+    const float cs = a.info->cs;
+
+    const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+    int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
+    if (span1 > a.nspans) span1 = a.nspans;
+    const int npass = (int)(span1 - span0) * PPS;
+    const int nsteps = npass * nK;
+
+    const float INF = __builtin_inff();
+    float NEG_INF = -INF;
+    asm volatile("" : "+v"(NEG_INF));
+    unsigned idmask = kQuadIdMask;
+    asm volatile("" : "+v"(idmask));
+    float m1[CB], m2[CB], M1[CB], M2[CB];
+    int Ms[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        m1[cb] = m2[cb] = M1[cb] = M2[cb] = INF;
+        Ms[cb] = 0;
+    }
+
+    const int lane16 = lane * 16;
+    auto stage_issue = [&](int step, int buf) {             // A panels of K-step `step` -> LDS slot
+        const int pass = step / nK, kk = step - pass * nK;
+        const int64_t tile0 = (span0 + pass / PPS) * kTilesPerSpan16 + (pass % PPS) * HT;
+        const half8 *base = ABL == 3 ? a.panels : a.panels + ((size_t)tile0 * KS + kk * 2) * 64;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(base), 0, 0x7fffffff, 0x00020000);
+        half8 *dst = lds_a(buf);
+#pragma unroll
+        for (int i = 0; i < (HT * 2) / NWAVES; ++i) {
+            const int p = wave + i * NWAVES;                // piece = (tile t, k-step ks)
+            const int t = p >> 1, ks = p & 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, lane16, ABL == 3 ? p * 1024 : (t * KS + ks) * 1024, 0, 0);
+        }
+    };
+
+    float4v acc[HT][CB];
+    half8 bq[CB][2];          // B fragments of the current K-step, reloaded in place (see scan_kloop_kernel)
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half8 *>(a.qpanels + (size_t)(q0 / 16) * KS * 64), 0, 0x7fffffff, 0x00020000);
+    auto load_b = [&](int kk, int ks) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            bq[cb][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rsq, lane16, (cb * KS + (ABL == 3 ? 0 : kk * 2) + ks) * 1024, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+        if (i < nsteps) stage_issue(i, i);
+    load_b(0, 0);
+    __syncthreads();
+
+    half8 fr[2][4];
+    auto read_group = [&](int buf, int grp, half8(&dst)[4]) {   // group grp = (ks = grp>>1, tiles 4*(grp&1)..+3)
+        const half8 *A = lds_a(buf);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t] = A[(((grp & 1) * 4 + t) * 2 + (grp >> 1)) * 64 + lane];
+    };
+    read_group(0, 0, fr[0]);
+
+    int step = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int64_t span = span0 + pass / PPS;
+        const int slice = pass % PPS;
+        // accumulators start from the bias of their rows: row = 1024*span + 256*g + 4*(HT*slice + t) + i
+#pragma unroll
+        for (int t = 0; t < (ABL == 4 ? 0 : HT); ++t) {
+            const float4 c = *reinterpret_cast<const float4 *>(a.bias + span * kSpanRows16 + g * kBinRows +
+                                                               (slice * HT + t) * 4);
+            acc[t][0][0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
+            acc[t][0][1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
+            acc[t][0][2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
+            acc[t][0][3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
+#pragma unroll
+            for (int cb = 1; cb < CB; ++cb) acc[t][cb] = acc[t][0];
+        }
+#pragma unroll 1   // (unrolled, hipcc hoists the next K-step's loads across the body and spills)
+        for (int kk = 0; kk < nK; ++kk, ++step) {
+            const int buf = step % RING;
+            load_b(kk, 1);
+            stage_issue(step + BS < nsteps ? step + BS : nsteps - 1, (step + BS) % RING);
+            const int kn = (kk + 1 == nK) ? 0 : kk + 1;      // B repeats every pass
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp < 3) {
+                    read_group(buf, grp + 1, fr[(grp + 1) & 1]);
+                } else {
+                    if (BS == 1 || (step % BS) == BS - 1) __syncthreads();
+                    read_group((step + 1) % RING, 0, fr[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        if (ABL != 2)
+                            acc[(grp & 1) * 4 + t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                fr[grp & 1][t], bq[cb][grp >> 1], acc[(grp & 1) * 4 + t][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 1) load_b(kn, 0);
+            }
+        }
+        if (ABL == 4) {      // keep the accumulators alive with one cheap use
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) m1[cb] = fast_min(m1[cb], acc[t][cb][0], NEG_INF);
+        }
+#pragma unroll
+        for (int t = 0; t < (ABL == 4 ? 0 : HT); ++t) {
+            const unsigned id = (unsigned)(slice * HT + t);     // tile number inside the span = quad number in the bin
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
+                                          fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
+                const float v = pack_score(qm, idmask, id);
+                m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
+                m1[cb] = fast_min(m1[cb], v, NEG_INF);
+            }
+        }
+        if (slice == PPS - 1) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const size_t o = (size_t)(span * 4 + g) * a.Qpad + q0 + cb * 16 + (lane & 15);
+                a.bin_m1[o] = m1[cb];
+                a.bin_m2[o] = m2[cb];
+                M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+                M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+                m1[cb] = INF;
+                m2[cb] = INF;
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const size_t so = (size_t)(chunk * 4 + g) * a.Qpad + q0 + cb * 16 + (lane & 15);
+        a.sb_m1[so] = M1[cb];
+        a.sb_m2[so] = M2[cb];
+        a.sb_span[so] = Ms[cb];
+    }
+}
+
+}  // namespace vdb

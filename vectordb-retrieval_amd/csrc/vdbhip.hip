@@ -12,6 +12,7 @@
 #include "prep.hpp"
 #include "refine.hpp"
 #include "scan.hpp"
+#include "scan16.hpp"
 #include "ivf.hpp"
 #include "ivf_mfma.hpp"
 #include "dense.hpp"
@@ -81,6 +82,8 @@ struct vdb_index_s {
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
     // options
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
+    int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
+    bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
     // per-search
     Workspace ws;
     vdb_stats_t last{};
@@ -185,7 +188,10 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     h->built = false;
     h->N = n;
     h->id_base = id_base;
-    h->Npad = (n + kSpanRows - 1) / kSpanRows * kSpanRows;
+    // D > 128 (K-loop scan): p16 panels for v_mfma_f32_16x16x32_f16; D <= 128: 32-row tiles (scan_kernel, dense path)
+    h->tile16 = h->ksteps > kMaxKSteps && h->layout_override != 1;
+    const int64_t span_rows = h->tile16 ? kSpanRows16 : kSpanRows;
+    h->Npad = (n + span_rows - 1) / span_rows * span_rows;
     h->scan_ok = false;
     if (n == 0) {
         h->built = true;
@@ -198,10 +204,14 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     index_stats(h, st);
     const bool dims_ok = D <= 4096;
     if (dims_ok && !h->nonfinite) {
-        const int64_t ntiles = h->Npad / kTileRows;
-        h->panels.reserve((size_t)ntiles * h->ksteps * 64 * sizeof(half8));
-        const int64_t threads = ntiles * h->ksteps * 64;
-        build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
+        const int64_t ntiles = h->Npad / (h->tile16 ? kTileRows16 : kTileRows);
+        const int ksl = h->tile16 ? h->ksteps / 2 : h->ksteps;          // k-steps of the layout (32 or 16 dims)
+        h->panels.reserve((size_t)ntiles * ksl * 64 * sizeof(half8));
+        const int64_t threads = ntiles * ksl * 64;
+        if (h->tile16)
+            build_panels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, ksl, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
+        else
+            build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
         VDB_HIP(hipGetLastError());
         h->bias.reserve((size_t)h->Npad * sizeof(float));
         build_bias_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(h->xnorm2.as<float>(), n, h->Npad, h->metric, h->bias.as<float>());
@@ -224,26 +234,27 @@ struct ScanGeom {
 
 ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     ScanGeom g;
-    g.nspans = h->Npad / kSpanRows;
-    if (g.nspans < 8) return g;
-    // superbins (2 per chunk) must comfortably outnumber k and fit 16 values per lane in the select
-    int64_t spc_hi = g.nspans / (2 * (int64_t)k);           // nsb >= 4k
-    int64_t spc_lo = (g.nspans + 511) / 512;                // nsb <= 1024
+    const int G = h->tile16 ? 4 : 2;                        // bins (lane groups) per span
+    g.nspans = h->Npad / (G * kBinRows);
+    if (g.nspans * G < 16) return g;
+    // superbins (G per chunk) must comfortably outnumber k and fit 16 values per lane in the select
+    int64_t spc_hi = g.nspans * G / (4 * (int64_t)k);       // nsb >= 4k
+    int64_t spc_lo = (g.nspans * G + 1023) / 1024;          // nsb <= 1024
     if (spc_hi < 1 || spc_hi < spc_lo) return g;
-    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : 16, spc_hi);
+    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : 32 / G, spc_hi);   // 8192 rows per chunk
     spc = std::max<int64_t>(spc, spc_lo);
-    if (spc < 2 && g.nspans >= 64) spc = std::min<int64_t>(2, spc_hi);
+    if (spc < 2 && g.nspans * G >= 128) spc = std::min<int64_t>(2, spc_hi);
     int64_t nchunks = (g.nspans + spc - 1) / spc;
     // deal the spans evenly over a multiple of 8 chunks (one XCD label each, see scan_kernel) when possible
     if (nchunks >= 16) {
         int64_t n8 = (nchunks + 7) / 8 * 8;
-        if (n8 <= 512 && g.nspans / n8 >= 1) nchunks = n8;   // (more chunks only add superbins)
+        if (n8 * G <= 1024 && g.nspans / n8 >= 1) nchunks = n8;   // (more chunks only add superbins)
     }
     g.nchunks = (int)nchunks;
     g.spc = (int)(g.nspans / nchunks);
     g.rem = (int)(g.nspans - (int64_t)g.spc * nchunks);
     if (g.spc < 1) return g;
-    const int nsb = 2 * g.nchunks;
+    const int nsb = G * g.nchunks;
     g.vpl = 1;
     while (g.vpl * 64 < nsb) g.vpl *= 2;
     if (g.vpl > 16) return g;
@@ -282,13 +293,24 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
     if (h->ksteps > kMaxKSteps) {  // D > 128
         // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
         // option kloop_qgroup = query tiles per group of the block order (0 -> default)
-        const bool wide = h->scan_variant != 1 && h->scan_variant != 4;   // 512-query tiles
+        const bool wide = h->tile16 || (h->scan_variant != 1 && h->scan_variant != 4);   // 512-query tiles
         sa.nqtiles = (int)(Qpad / (wide ? 512 : 256));
         int qgroup = h->kloop_qgroup > 0 ? h->kloop_qgroup : (wide ? 4 : sa.nqtiles);
         qgroup = std::min(qgroup, sa.nqtiles);
         const unsigned ngroups = (unsigned)((sa.nqtiles + qgroup - 1) / qgroup);
         const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * ngroups * (unsigned)qgroup;
         const ScanKloopExtra ex{h->ksteps, qgroup};
+        if (h->tile16) {
+            switch (h->scan_variant) {
+                case 2: scan16_kloop_kernel<0, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+                case 7: scan16_kloop_kernel<2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
+                case 8: scan16_kloop_kernel<3, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
+                case 9: scan16_kloop_kernel<4, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
+                default: scan16_kloop_kernel<0, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+            }
+            VDB_HIP(hipGetLastError());
+            return;
+        }
         switch (h->scan_variant) {
             case 1: scan_kloop_kernel<0, 8, 1, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             case 2: scan_kloop_kernel<0, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
@@ -507,7 +529,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 
     // ---- MFMA scan path ------------------------------------------------------------------------------
     const int64_t Qpad = (nq + 511) / 512 * 512;
-    const int64_t nbins = g.nspans * 2, nsb = (int64_t)g.nchunks * 2;
+    const int G = h->tile16 ? 4 : 2;
+    const int64_t nbins = g.nspans * G, nsb = (int64_t)g.nchunks * G;
     const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
     const int rescan_cap = std::max(16, k / 2 + 8);
     ws.info.reserve(sizeof(QueryBatchInfo));
@@ -531,8 +554,11 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 512);
         query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2);
-        const int64_t threads = (Qpad / 32) * h->ksteps * 64;
-        build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, h->ksteps, Qpad / 32, info, ws.qpanels.as<half8>());
+        const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
+        if (h->tile16)
+            build_qpanels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, h->ksteps / 2, Qpad / 16, info, ws.qpanels.as<half8>());
+        else
+            build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, h->ksteps, Qpad / 32, info, ws.qpanels.as<half8>());
         EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
                    h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
         query_eps_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(ea);
@@ -581,6 +607,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.chunk_rem = g.rem;
     se.nchunks = g.nchunks;
     se.k = k;
+    se.groups = G;
     se.cand_cap = cand_cap;
     se.rescan_cap = rescan_cap;
     se.cand_rows = ws.cand.as<int32_t>();
@@ -590,7 +617,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_list = ws.fb_list.as<int32_t>();
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
-    const int nsb_i = 2 * g.nchunks;
+    const int nsb_i = G * g.nchunks;
     if (nsb_i <= 256 && h->select_variant == 0) {  // multi-lane form: 16 lanes per query, 4 queries per wave
         const unsigned sgrid = (unsigned)((nq + 15) / 16);
         if (nsb_i <= 64)
@@ -1033,6 +1060,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "timing") {  // (re)starts the recording window
             h->timing = value != 0;
             h->ev_used = 0;
+        } else if (k == "panel_layout") {   // 0 auto, 1 = 32-row tiles for every D (takes effect at the next add)
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_layout must be 0 or 1");
+            h->layout_override = (int)value;
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;
