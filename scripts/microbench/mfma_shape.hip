@@ -24,7 +24,7 @@ __device__ __forceinline__ void quad(float a, float b, float c, float d, unsigne
     m1 = __builtin_amdgcn_fmed3f(m1, v, ninf);
 }
 
-template <int SHAPE, bool EPI>
+template <int SHAPE, bool EPI, bool BIAS = false>
 __global__ __launch_bounds__(512, 2) void loop_kernel(const half8 *A, const half8 *B, float *out, int iters) {
     __shared__ half8 lds[kTiles * 8 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,6 +40,15 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const half8 *A, const half
 #pragma unroll 1
             for (int t = 0; t < kTiles; ++t) {
                 float16v acc0 = {0}, acc1 = {0};
+                if (BIAS) {   // accumulator init from 16 per-row biases, four broadcast ds_read_b128 (as scan_kernel does)
+                    const float4 *bp = reinterpret_cast<const float4 *>(lds) + ((t * 37 + (lane >> 5) * 4) & 1023);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 c = bp[g];
+                        acc0[4 * g] = c.x; acc0[4 * g + 1] = c.y; acc0[4 * g + 2] = c.z; acc0[4 * g + 3] = c.w;
+                    }
+                    acc1 = acc0;
+                }
                 const half8 *a = lds + t * 8 * 64 + lane;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -105,13 +114,15 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flops = (double)nblk * 8 * iters * kTiles * 16 * 32768.0;   // per wave and unit: 16 MFMA 32x32x16
     for (int round = 0; round < 3; ++round)
-      for (int epi = 0; epi < 2; ++epi)
+      for (int epi = 0; epi < 3; ++epi)
         for (int shape : {32, 16}) {
+            if (epi == 2 && shape == 16) continue;   // (bias variant: 32x32 only)
             float best = 1e30f;
             for (int rep = 0; rep < 5; ++rep) {
                 CK(hipEventRecord(e0));
                 if (shape == 32 && !epi) loop_kernel<32, false><<<nblk, 512>>>(dA, dB, dO, iters);
-                else if (shape == 32) loop_kernel<32, true><<<nblk, 512>>>(dA, dB, dO, iters);
+                else if (shape == 32 && epi == 1) loop_kernel<32, true><<<nblk, 512>>>(dA, dB, dO, iters);
+                else if (shape == 32) loop_kernel<32, true, true><<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (!epi) loop_kernel<16, false><<<nblk, 512>>>(dA, dB, dO, iters);
                 else loop_kernel<16, true><<<nblk, 512>>>(dA, dB, dO, iters);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));

@@ -390,3 +390,27 @@ def test_candidate_rerank_matches_reference_loop(vdb):
             np.testing.assert_allclose(d[r, :n], want, rtol=2e-6, atol=1e-6)
             assert np.all(i[r, n:] == -1) and np.all(np.isinf(d[r, n:]))
         idx.close()
+
+
+@pytest.mark.parametrize("d,metric,kind", [(128, "l2", "sift"), (100, "l2", "gauss"), (50, "ip", "glove"), (64, "ip", "gauss")])
+def test_p16_panel_layout_for_small_dims_is_exact(vdb, oracle, d, metric, kind):
+    """Option panel_layout = 2: 16-row-tile panels + scan16_kernel (v_mfma_f32_16x16x32_f16) for D <= 128 -- the
+    measured-and-not-adopted alternative of DESIGN 4.3.  Same bins, ids and guard: bit-exact results, and the
+    per-query error bound holds on its raw scores."""
+    X, Q = _make(40000, d, 150, kind, 21)
+    idx = vdb.FlatIndex(d, metric, 0)
+    idx.set_option("panel_layout", 2)
+    idx.add(X, id_base=5)
+    for k in (1, 10, 37):
+        D, I = idx.search(Q, k)
+        Do, Io = oracle.knn(X, Q, k, metric, id_base=5)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+        assert idx.stats()["last_path_name"] == "mfma_scan"
+    scores, eps, cs = idx.debug_scan_scores(Q[:32], 1024, 3000)
+    X64, Q64 = X[1024:4024].astype(np.float64), Q[:32].astype(np.float64)
+    dots = Q64 @ X64.T
+    exact = ((X64 * X64).sum(1)[None, :] - 2.0 * dots) if metric == "l2" else -dots
+    err = np.abs(scores.astype(np.float64) / cs - exact)
+    assert np.all(err <= (eps.astype(np.float64) / cs)[:, None])
+    idx.close()

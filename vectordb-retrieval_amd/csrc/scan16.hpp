@@ -15,6 +15,197 @@ namespace vdb {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+// ---- flat scan for D <= 128 on p16 panels ---------------------------------------------------------------
+// Same workgroup geometry and phase stagger as scan_kernel: 8 waves = (corpus chunk) x (512-query tile), wave w
+// owns 64 queries as four 16-query column blocks whose B fragments stay in registers for the whole chunk
+// (KS x 4 x 4 VGPRs).  A tile is 16 rows: KS A fragments (ds_read_b128) + one broadcast ds_read_b128 of the 4
+// biases of the lane's rows, 4*KS v_mfma_f32_16x16x32_f16, and a select phase of 4 quads (one per column
+// block): 3 + 1 + 2 VALU each.  ST tiles per LDS stage (DMA, double buffered, one barrier per stage); the four
+// 256-row bins (span, g) of a span complete together after its 64th tile.
+// ABL: timing-only builds (wrong results): 1 = no select, 2 = no MFMA.
+template <int KS, int ST, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void scan16_kernel(ScanArgs a) {
+    constexpr int NWAVES = 8, NT = 512, CB = 4;
+    constexpr int kStageVec = ST * KS * 64;                  // 16-byte vectors per stage
+    constexpr int SPS = kTilesPerSpan16 / ST;                // stages per span
+    constexpr int kPieces = ST * KS;                         // 1-KiB pieces per stage
+    static_assert(kTilesPerSpan16 % ST == 0 && kPieces % NWAVES == 0 && ST * 16 <= NT, "bad geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 16 * 4)];
+    auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
+    auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 16 * 4)); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const bool late = wave >= NWAVES / 2;
+    const int b = blockIdx.x;
+    const int x = b & 7, j = b >> 3;
+    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+    const int chunk = x + 8 * ci;
+    if (chunk >= a.nchunks) return;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;
+    const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+    int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
+    if (span1 > a.nspans) span1 = a.nspans;
+    const float cs = a.info->cs;
+
+    half8 bq[CB][KS];                                        // B fragments: resident for the whole chunk
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 16 + cb) * KS + ks) * 64 + lane];
+
+    const int nstages = (int)(span1 - span0) * SPS;
+    const float INF = __builtin_inff();
+    float NEG_INF = -INF;
+    asm volatile("" : "+v"(NEG_INF));  // opaque, or LLVM folds med3(a,b,-inf) back into a canonicalising fmin
+    unsigned idmask = kQuadIdMask;
+    asm volatile("" : "+v"(idmask));
+    float m1[CB], m2[CB], M1[CB], M2[CB];
+    int Ms[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        m1[cb] = m2[cb] = M1[cb] = M2[cb] = INF;
+        Ms[cb] = 0;
+    }
+
+    const int lane16 = lane * 16;
+    float stage_bv = 0.f;
+    auto stage_issue = [&](int st, int buf) {
+        const int64_t span = span0 + st / SPS;
+        const int sq = st % SPS;
+        const half8 *base = a.panels + ((size_t)(span * kTilesPerSpan16 + sq * ST) * KS) * 64;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(base), 0, 0x7fffffff, 0x00020000);
+        half8 *dst = lds_a(buf);
+#pragma unroll
+        for (int i = 0; i < kPieces / NWAVES; ++i) {
+            const int p = wave + i * NWAVES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs, reinterpret_cast<__attribute__((address_space(3))) void *>(
+                        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, lane16, p * 1024, 0, 0);
+        }
+        if (tid < ST * 16) {   // bias of (tile t, MFMA row rho = 4 gg + i): raw value only (no use before the DMA wait)
+            const int t = tid >> 4, gg = (tid >> 2) & 3, i = tid & 3;
+            stage_bv = a.bias[span * kSpanRows16 + gg * kBinRows + (sq * ST + t) * 4 + i];
+        }
+    };
+    auto stage_bias_store = [&](int buf) {
+        if (tid < ST * 16) lds_b(buf)[tid] = (stage_bv >= 0.9e38f) ? kPadBias : stage_bv * cs;
+    };
+    auto flush_bins = [&](int64_t span) {     // the four bins (span, g) are complete: write them, fold level 2
+        const size_t o = (size_t)(span * 4 + g) * a.Qpad + q0 + (lane & 15);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            a.bin_m1[o + cb * 16] = m1[cb];
+            a.bin_m2[o + cb * 16] = m2[cb];
+            M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+            M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
+            m1[cb] = INF;
+            m2[cb] = INF;
+        }
+    };
+
+    half8 fr[KS];
+    float4v cin, acc[CB];
+    auto read_phase = [&](const half8 *A_tile, const float *b_tile) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fr[ks] = A_tile[ks * 64 + lane];
+        const float4 c = *reinterpret_cast<const float4 *>(b_tile + 4 * g);
+        cin[0] = c.x; cin[1] = c.y; cin[2] = c.z; cin[3] = c.w;
+    };
+    auto mfma_phase = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                if (ABL != 2)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], bq[cb][ks], ks == 0 ? cin : acc[cb], 0, 0, 0);
+                else
+                    acc[cb] = (ks == 0 ? cin : acc[cb]) + (float)fr[ks][0] * (float)bq[cb][ks][0];
+            }
+    };
+    auto select_phase = [&](unsigned id) {   // id = tile number inside the span = quad number inside the bin
+        if (ABL == 1) {
+            asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+            return;
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const float qm = fast_min(fast_min(acc[cb][0], acc[cb][1], NEG_INF), fast_min(acc[cb][2], acc[cb][3], NEG_INF),
+                                      NEG_INF);
+            const float v = pack_score(qm, idmask, id);
+            m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
+            m1[cb] = fast_min(m1[cb], v, NEG_INF);
+        }
+    };
+
+    stage_issue(0, 0);
+    stage_bias_store(0);
+    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+
+    if (!late) {
+        // ================= early half: MFMA(t), then select(t) =======================================
+#pragma unroll 1
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);  // buf^1 was last read before the previous barrier
+            const half8 *A = lds_a(buf);
+            const float *Bv = lds_b(buf);
+            const int ts0 = (st % SPS) * ST;                     // first tile of this stage inside its span
+            read_phase(A, Bv);
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < ST) read_phase(A + (t + 1) * KS * 64, Bv + (t + 1) * 16);
+                select_phase((unsigned)(ts0 + t));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ts0 + ST == kTilesPerSpan16) flush_bins(span0 + st / SPS);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // ================= late half: select(t-1), then MFMA(t) =====================================
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = float4v{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};  // dummy previous tile
+#pragma unroll 1
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const half8 *A = lds_a(buf);
+            const float *Bv = lds_b(buf);
+            const int ts0 = (st % SPS) * ST;
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_phase(A + t * KS * 64, Bv + t * 16);
+                // retire the previous tile (the last tile of the previous span when ts0 + t == 0)
+                select_phase((unsigned)((ts0 + t + kTilesPerSpan16 - 1) % kTilesPerSpan16));
+                if (t == 0 && st > 0 && ts0 == 0) flush_bins(span0 + st / SPS - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
+        }
+        select_phase((unsigned)(kTilesPerSpan16 - 1));  // drain the last tile
+        flush_bins(span1 - 1);
+    }
+
+    const size_t so = (size_t)(chunk * 4 + g) * a.Qpad + q0 + (lane & 15);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        a.sb_m1[so + cb * 16] = M1[cb];
+        a.sb_m2[so + cb * 16] = M2[cb];
+        a.sb_span[so + cb * 16] = Ms[cb];
+    }
+}
+
 // ---- K-loop scan for D > 128 on p16 panels ---------------------------------------------------------------
 // Workgroup = 8 waves = (corpus chunk) x (512-query tile); wave w owns four 16-query column blocks and, per pass,
 // eight 16-row tiles (8 x 4 x 4 = 128 accumulator registers: a 128-row x 64-query output tile, as the 32x32 form).

@@ -189,7 +189,8 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     h->N = n;
     h->id_base = id_base;
     // D > 128 (K-loop scan): p16 panels for v_mfma_f32_16x16x32_f16; D <= 128: 32-row tiles (scan_kernel, dense path)
-    h->tile16 = h->ksteps > kMaxKSteps && h->layout_override != 1;
+    // (panel_layout 2 = p16 for D <= 128 too, when the corpus is too large for the dense small-corpus kernel)
+    h->tile16 = h->layout_override != 1 && (h->ksteps > kMaxKSteps || (h->layout_override == 2 && n > 8192));
     const int64_t span_rows = h->tile16 ? kSpanRows16 : kSpanRows;
     h->Npad = (n + span_rows - 1) / span_rows * span_rows;
     h->scan_ok = false;
@@ -320,6 +321,20 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
             case 7: scan_kloop_kernel<2, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
             case 8: scan_kloop_kernel<3, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
             default: scan_kloop_kernel<0, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+        }
+    } else if (h->tile16) {            // D <= 128 on p16 panels
+        sa.nqtiles = (int)(Qpad / 512);
+        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
+        const int v = h->scan_variant;
+        if (h->ksteps == 4) {
+            if (v == 7) scan16_kernel<2, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else if (v == 8) scan16_kernel<2, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else scan16_kernel<2, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
+        } else {
+            if (v == 7) scan16_kernel<4, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else if (v == 8) scan16_kernel<4, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else if (v == 1) scan16_kernel<4, 4><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
         }
     } else if (h->ksteps == 4)
         launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st);
@@ -1060,8 +1075,8 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "timing") {  // (re)starts the recording window
             h->timing = value != 0;
             h->ev_used = 0;
-        } else if (k == "panel_layout") {   // 0 auto, 1 = 32-row tiles for every D (takes effect at the next add)
-            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_layout must be 0 or 1");
+        } else if (k == "panel_layout") {   // 0 auto, 1 = 32-row tiles for every D, 2 = p16 for every D (next add)
+            if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "panel_layout must be 0, 1 or 2");
             h->layout_override = (int)value;
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
