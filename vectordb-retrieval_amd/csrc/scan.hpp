@@ -794,10 +794,18 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                 const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
                 int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
                 if (sp1 > a.nspans) sp1 = a.nspans;
-                for (int64_t sp = sp0; sp < sp1; ++sp) {
-                    const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
-                    const float bm1 = a.bin_m1[o];
+                for (int64_t spb = sp0; spb < sp1; spb += 8) {
+                  // (8 independent loads in flight: the bins of a chunk used to be fetched one dependent load at a time)
+                  float bm1v[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                      bm1v[u] = (spb + u < sp1) ? a.bin_m1[(size_t)((spb + u) * a.groups + hh) * a.Qpad + q] : __builtin_inff();
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const int64_t sp = spb + u;
+                    const float bm1 = bm1v[u];
                     if (!(bm1 <= that)) continue;
+                    const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
                     if (a.bin_m2[o] <= that) {
                         const int pos = atomicAdd(cnt_r, 1);
                         if (pos < a.rescan_cap) {
@@ -809,6 +817,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                         if (pos < a.cand_cap)
                             cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                     }
+                  }
                 }
             }
         }
