@@ -1,0 +1,111 @@
+"""Randomised parity sweep: seeded shapes / value distributions across every search path of the flat index (exhaustive
+exact, dense small-corpus, MFMA scan, K-loop scan) against the CPU oracle -- ids and distances bit for bit.
+Deterministic (fixed seeds); sized so the oracle side finishes in seconds."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _values(rng, kind, shape):
+    if kind == "gauss":
+        return rng.standard_normal(shape)
+    if kind == "ints":            # SIFT-like: exact in fp16, unscaled
+        return np.clip(np.rint(rng.gamma(0.6, 40.0, size=shape)), 0, 218)
+    if kind == "bigints":         # integers beyond the unscaled fp16 range
+        return np.rint(rng.standard_normal(shape) * 3000.0)
+    if kind == "tiny":
+        return rng.standard_normal(shape) * 1e-4
+    if kind == "huge":
+        return rng.standard_normal(shape) * 1e5
+    if kind == "heavy":           # heavy tails: a few coordinates dominate the norms
+        return np.clip(rng.standard_cauchy(shape), -1e3, 1e3)
+    if kind == "sparse":          # mostly zeros
+        return rng.standard_normal(shape) * (rng.random(shape) < 0.05)
+    if kind == "offset":          # large common offset, small spread (cancellation in ||x||^2 - 2 q.x)
+        return 50.0 + rng.standard_normal(shape) * 0.1
+    raise AssertionError(kind)
+
+
+KINDS = ["gauss", "ints", "bigints", "tiny", "huge", "heavy", "sparse", "offset"]
+
+
+def _cases():
+    rng = np.random.default_rng(20240607)
+    out = []
+    # (n range, d range, nq range) per targeted path
+    targets = [
+        ((1, 3000), (1, 260), (1, 40)),            # exhaustive exact kernel
+        ((600, 8192), (2, 128), (64, 200)),        # dense small-corpus MFMA path
+        ((32768, 70000), (3, 128), (1, 200)),      # flat MFMA scan
+        ((32768, 50000), (129, 300), (1, 120)),    # K-loop MFMA scan (p16 panels)
+    ]
+    for t, (nr, dr, qr) in enumerate(targets):
+        for i in range(10):
+            n = int(rng.integers(nr[0], nr[1] + 1))
+            d = int(rng.integers(dr[0], dr[1] + 1))
+            nq = int(rng.integers(qr[0], qr[1] + 1))
+            k = int(min(n + 3, rng.choice([1, 2, 5, 10, 33, 100])))
+            out.append((t, i, n, d, nq, k, str(rng.choice(["l2", "ip"])), str(rng.choice(KINDS))))
+    return out
+
+
+@pytest.mark.parametrize("target,i,n,d,nq,k,metric,kind", _cases())
+def test_random_shapes_and_distributions_bit_exact(oracle, target, i, n, d, nq, k, metric, kind):
+    import vdbhip
+
+    rng = np.random.default_rng(1000 * target + i)
+    X = _values(rng, kind, (n, d)).astype(np.float32)
+    Q = _values(rng, kind, (nq, d)).astype(np.float32)
+    if n > 10 and i % 3 == 0:      # duplicates, zero rows and a query that IS a corpus row
+        X[n // 2] = X[n // 3]
+        X[n // 5] = 0.0
+        Q[0] = X[n // 7]
+    idx = vdbhip.FlatIndex(d, metric, 0)
+    idx.add(X, id_base=11)
+    D, I = idx.search(Q, k)
+    Do, Io = oracle.knn(X, Q, k, metric, id_base=11)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    idx.close()
+
+
+def _ivf_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for i in range(12):
+        n = int(rng.integers(2000, 70000))
+        d = int(rng.integers(2, 200))
+        nlist = int(rng.integers(2, min(400, n // 20)))
+        nq = int(rng.integers(1, 400))
+        k = int(rng.choice([1, 5, 10, 50]))
+        out.append((i, n, d, nlist, int(rng.integers(1, nlist + 1)), nq, k, str(rng.choice(["l2", "ip"])),
+                    str(rng.choice(["gauss", "ints", "heavy", "offset", "sparse"]))))
+    return out
+
+
+@pytest.mark.parametrize("i,n,d,nlist,nprobe,nq,k,metric,kind", _ivf_cases())
+def test_random_ivf_configurations_bit_exact(oracle, i, n, d, nlist, nprobe, nq, k, metric, kind):
+    """IVF-Flat with injected centroids == brute force restricted to the probed lists (oracle/ivf_oracle.c), for random
+    list counts (including empty and tiny lists), probe counts, dims on both sides of the MFMA list-scan limits."""
+    import vdbhip
+
+    rng = np.random.default_rng(500 + i)
+    X = _values(rng, kind, (n, d)).astype(np.float32)
+    Q = _values(rng, kind, (nq, d)).astype(np.float32)
+    C = X[rng.choice(n, nlist, replace=False)].copy()
+    if i % 4 == 0:
+        C[0] = 1e4            # a centroid far from everything: an empty list
+    idx = vdbhip.IVFFlatIndex(d, nlist, metric, 0)
+    idx.set_centroids(C)
+    idx.add(X, id_base=3)
+    lor = idx.assignment()
+    np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, metric))
+    idx.set_nprobe(nprobe)
+    D, I = idx.search(Q, k)
+    Do, Io = oracle.ivf_search(X, C, lor, Q, k, nprobe, metric, id_base=3)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    idx.close()
