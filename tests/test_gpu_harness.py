@@ -81,3 +81,33 @@ def test_ground_truth_through_the_kernel(oracle, tmp_path):
     np.testing.assert_array_equal(gt[:20, :100], rs.ground_truth_l2(X, Q[:20], 100))
     gtc = harness.ground_truth(X, Q, k=100, metric="ip", normalize=True)
     np.testing.assert_array_equal(gtc, oracle.knn(rs.safe_normalize(X), rs.safe_normalize(Q), 100, "ip")[1].astype(np.int32))
+
+
+def test_local_file_datasets_fvecs_and_npy(oracle, tmp_path):
+    """Datasets from local .fvecs / .ivecs / .npy files through the reference-shaped config:
+    the stored ground truth is used when present, otherwise it is computed by the exact kernel path."""
+    from vdbhip import harness, io
+
+    rng = np.random.default_rng(4)
+    X = np.rint(rng.standard_normal((40000, 24)) * 20).astype(np.float32)
+    Q = np.rint(rng.standard_normal((120, 24)) * 20).astype(np.float32)
+    gt = oracle.knn(X, Q, 100, "l2")[1].astype(np.int32)
+    io.write_fvecs(tmp_path / "base.fvecs", X)
+    io.write_fvecs(tmp_path / "query.fvecs", Q)
+    io.write_ivecs(tmp_path / "gt.ivecs", gt)
+    np.save(tmp_path / "base.npy", X)
+    np.save(tmp_path / "query.npy", Q)
+    base = {"topk": 10, "algorithms": {"exact": {"type": "HipExactSearch", "metric": "l2"},
+                                        "ivf": {"type": "HipApproximateSearch", "index_type": "IVF64,Flat",
+                                                "metric": "l2", "nprobe": 64}}}
+    cfg1 = dict(base, datasets=[{"name": "sift_local", "metric": "l2", "dataset_options": {
+        "train_path": str(tmp_path / "base.fvecs"), "test_path": str(tmp_path / "query.fvecs"),
+        "groundtruth_path": str(tmp_path / "gt.ivecs")}}])
+    cfg2 = dict(base, datasets=[{"name": "npy_local", "metric": "l2", "dataset_options": {
+        "train_path": str(tmp_path / "base.npy"), "test_path": str(tmp_path / "query.npy"), "ground_truth_k": 50}}])
+    for cfg, name in ((cfg1, "sift_local"), (cfg2, "npy_local")):
+        res = harness.run_benchmark(cfg)[name]
+        assert res["exact"]["recall@10"] == 1.0 and res["exact"]["n_train"] == 40000 and res["exact"]["n_test"] == 120
+        assert res["ivf"]["recall@10"] == 1.0          # nprobe = nlist: IVF degenerates to brute force
+    with pytest.raises(ValueError, match="needs local files"):
+        harness.run_benchmark(dict(base, datasets=[{"name": "sift1m"}]))

@@ -8,7 +8,9 @@ Mirrors the part of ExperimentRunner that drives the hot path (src/experiments/e
   k <= topk (evaluation.py:23-29, 47-50).
 and the YAML shapes of configs/*.yaml (runner.py:95-155, 274-299): top-level `indexers`, `searchers`,
 `algorithms`, `datasets[]`; an algorithm entry is {type, metric, ...kwargs} or {indexer_ref, searcher_ref}.
-Only synthetic `random` datasets (dataset.py:473-504 recipe) are generated here -- downloads are out of scope.
+Datasets: the synthetic `random` recipe (dataset.py:473-504), or LOCAL files named in `dataset_options`
+(`train_path` / `test_path` / optional `groundtruth_path`: `.fvecs` / `.ivecs` / `.npy`, read by io.py; missing ground
+truth is computed through the HIP kernels) -- downloads are out of scope.
 """
 from __future__ import annotations
 
@@ -160,13 +162,19 @@ def run_benchmark(config: Dict[str, Any]) -> Dict[str, Dict[str, Any]]:
     results: Dict[str, Dict[str, Any]] = {}
     for entry in config.get("datasets", [{"name": "random"}]):
         name = entry.get("name", "random")
-        if name != "random":
-            raise ValueError(f"dataset '{name}' needs files that are not available offline; only 'random' is generated")
         opts = entry.get("dataset_options", {}) or {}
-        dim, ntrain = int(opts.get("dimensions", 128)), int(opts.get("train_size", 10000))
-        ntest, gtk = int(opts.get("test_size", 1000)), int(opts.get("ground_truth_k", 100))
-        train, test = datasets.random_reference(dim, ntrain, ntest, int(opts.get("seed", 42)))
-        gt = np.stack([np.argsort(np.linalg.norm(train - q, axis=1))[:gtk] for q in test]).astype(np.int32)
+        gtk = int(opts.get("ground_truth_k", 100))
+        if name == "random":
+            dim, ntrain = int(opts.get("dimensions", 128)), int(opts.get("train_size", 10000))
+            ntest = int(opts.get("test_size", 1000))
+            train, test = datasets.random_reference(dim, ntrain, ntest, int(opts.get("seed", 42)))
+            gt = np.stack([np.argsort(np.linalg.norm(train - q, axis=1))[:gtk] for q in test]).astype(np.int32)
+        elif opts.get("train_path") and opts.get("test_path"):
+            train, test, gt = load_local_dataset(opts, gtk, entry.get("metric") or config.get("metric") or "l2")
+            dim, ntest = int(train.shape[1]), int(test.shape[0])
+        else:
+            raise ValueError(f"dataset '{name}' needs local files: give dataset_options.train_path / test_path "
+                             f"(.fvecs / .npy); nothing is downloaded")
         topk = int(entry.get("topk", config.get("topk", 10)))
         nq = int(entry.get("n_queries", config.get("n_queries", ntest)))
         qbs = int(entry.get("query_batch_size", config.get("query_batch_size", 0)))
@@ -192,6 +200,39 @@ def run_benchmark(config: Dict[str, Any]) -> Dict[str, Dict[str, Any]]:
             results[name][an] = run_single_algorithm(algo, train, test, gt, topk, qbs, name,
                                                      int(config.get("warmup_batches", 0)))["metrics"]
     return results
+
+
+def _load_rows(path: str, limit: Optional[int], integer: bool = False) -> np.ndarray:
+    from . import io
+
+    p = str(path)
+    if p.endswith(".fvecs"):
+        return io.read_fvecs(p, limit)
+    if p.endswith(".ivecs"):
+        return io.read_ivecs(p, limit)
+    if p.endswith(".npy"):
+        return io.open_npy_rows(p, limit)
+    raise ValueError(f"unsupported dataset file '{p}' (expected .fvecs, .ivecs or .npy)")
+
+
+def load_local_dataset(opts: Dict[str, Any], gtk: int, metric: str):
+    """(train, test, ground truth) from local files -- what Dataset.load does for sift1m / glove / msmarco once
+    the files exist (dataset.py:376-471, 522-574, 1001-1052), with the .fvecs payload read as float32 bits.
+    Ground truth comes from `groundtruth_path` (.ivecs / .npy) or, when absent or too narrow, from the exact
+    search itself (`ground_truth`, the kernel path of dataset.py:858-964)."""
+    train = _load_rows(opts["train_path"], opts.get("train_limit"))
+    test = _load_rows(opts["test_path"], opts.get("test_limit"))
+    if train.ndim != 2 or test.ndim != 2 or train.shape[1] != test.shape[1]:
+        raise ValueError(f"train {train.shape} and test {test.shape} do not agree on the dimension")
+    gt = None
+    if opts.get("groundtruth_path") and not opts.get("train_limit"):
+        gt = np.asarray(_load_rows(opts["groundtruth_path"], opts.get("test_limit")), dtype=np.int32)
+        if gt.shape[0] != test.shape[0] or gt.shape[1] < min(gtk, 10):
+            gt = None
+    if gt is None:
+        gt = ground_truth(train, test, k=min(gtk, train.shape[0]), metric=metric,
+                          normalize=bool(opts.get("normalize_cosine_groundtruth", False)) and metric == "cosine")
+    return train, test, gt
 
 
 def ground_truth(train: np.ndarray, test: np.ndarray, k: int = 100, metric: str = "l2",
