@@ -139,6 +139,9 @@ CASES = [
     (36000, 768, 80, 10, "ip", "gauss"),
     (50000, 384, 70, 5, "l2", "gauss"),
     (40000, 160, 64, 10, "ip", "gauss"),    # 192 padded dims: odd number of 64-dim K-steps
+    (20000, 64, 300, 10, "l2", "gauss"),    # 8192 < N < 32768: MFMA scan once nq*N >= 4e6 ...
+    (20000, 64, 100, 10, "l2", "gauss"),    # ... exhaustive exact kernel below that
+    (12000, 200, 400, 5, "ip", "gauss"),    # same rule on the K-loop path
     (40000, 128, 200, 10, "l2", "gauss"),   # MFMA scan path
     (40000, 128, 200, 10, "ip", "gauss"),
     (50000, 50, 130, 10, "ip", "glove"),
@@ -176,7 +179,10 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     # the bin select needs the superbins (two per >=512-row chunk) to outnumber k four to one
-    if n >= 32768 and (n + 511) // 512 >= 2 * k:
+    span = 1024 if d > 128 else 512              # p16 panels (D > 128) use 1024-row spans
+    npad = (n + span - 1) // span * span
+    big_batch = npad > 8192 and nq * n >= 4_000_000
+    if (n >= 32768 or big_batch) and npad // 256 >= 16 and npad // 256 >= 4 * k:
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st
     elif n <= 8192 and nq >= 64 and d <= 128 and 2 * k <= n:

@@ -390,7 +390,10 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     if (use_scan) g = scan_geometry(h, k);
     // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
     //  needs ~0.07 ms per query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
-    use_scan = use_scan && g.ok && (h->force_path == 2 || h->N >= 32768);
+    // Between the dense small-corpus path (<= 8192 rows) and 32768 rows the scan pays off once the batch carries
+    // enough (query, row) pairs: ~0.3 ms of fixed pipeline cost against ~7e-8 ms per pair in the exhaustive kernel.
+    use_scan = use_scan && g.ok &&
+               (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
 
     ws.small.reserve(64);
     VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
