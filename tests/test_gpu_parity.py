@@ -139,6 +139,8 @@ CASES = [
     (36000, 768, 80, 10, "ip", "gauss"),
     (50000, 384, 70, 5, "l2", "gauss"),
     (40000, 160, 64, 10, "ip", "gauss"),    # 192 padded dims: odd number of 64-dim K-steps
+    (9000, 128, 500, 10, "l2", "gauss"),    # 8192 < N <= 15360, too few superbins for the scan: dense path
+    (15000, 100, 70, 50, "ip", "gauss"),
     (20000, 64, 300, 10, "l2", "gauss"),    # 8192 < N < 32768: MFMA scan once nq*N >= 4e6 ...
     (20000, 64, 100, 10, "l2", "gauss"),    # ... exhaustive exact kernel below that
     (12000, 200, 400, 5, "ip", "gauss"),    # same rule on the K-loop path
@@ -185,7 +187,7 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     if (n >= 32768 or big_batch) and npad // 256 >= 16 and npad // 256 >= 4 * k:
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st
-    elif n <= 8192 and nq >= 64 and d <= 128 and 2 * k <= n:
+    elif npad <= 15360 and nq >= 64 and d <= 128 and 2 * k <= n:
         assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, st   # dense path
     else:
         assert st["last_path_name"] == "exact_scan", st

@@ -1,4 +1,4 @@
-// dense.hpp -- small-corpus path (N <= 8192 rows: IVF coarse quantizers, k-means assignment, tiny indexes).
+// dense.hpp -- small-corpus path (N <= 15360 rows: IVF coarse quantizers, k-means assignment, tiny indexes).
 //
 // With so few rows the bin-minimum select has nothing to work with (k is a sizeable fraction of N), so the
 // fp16 MFMA scores of ALL rows are written out (nq x Npad float32) and a per-query kernel keeps every row whose

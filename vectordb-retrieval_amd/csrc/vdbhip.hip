@@ -154,6 +154,8 @@ void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
     VDB_HIP(hipGetLastError());
 }
 
+constexpr int64_t kDenseMaxRows = 15360;   // dense small-corpus path: one query's scores fit the default 64 KiB of LDS
+
 // ---- index build ---------------------------------------------------------------------------------
 // exact row norms + corpus statistics of h->x32 (N rows) -> scales of the fp16 scan copy
 void index_stats(vdb_index_s *h, hipStream_t st) {
@@ -190,7 +192,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     h->id_base = id_base;
     // D > 128 (K-loop scan): p16 panels for v_mfma_f32_16x16x32_f16; D <= 128: 32-row tiles (scan_kernel, dense path)
     // (panel_layout 2 = p16 for D <= 128 too, when the corpus is too large for the dense small-corpus kernel)
-    h->tile16 = h->layout_override != 1 && (h->ksteps > kMaxKSteps || (h->layout_override == 2 && n > 8192));
+    h->tile16 = h->layout_override != 1 && (h->ksteps > kMaxKSteps || (h->layout_override == 2 && n > kDenseMaxRows));
     const int64_t span_rows = h->tile16 ? kSpanRows16 : kSpanRows;
     h->Npad = (n + span_rows - 1) / span_rows * span_rows;
     h->scan_ok = false;
@@ -394,6 +396,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     // enough (query, row) pairs: ~0.3 ms of fixed pipeline cost against ~7e-8 ms per pair in the exhaustive kernel.
     use_scan = use_scan && g.ok &&
                (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
+    // (corpora of 8193..15360 rows whose chunking cannot give 4k superbins still have the dense path below)
 
     ws.small.reserve(64);
     VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
@@ -404,7 +407,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 
     // small corpora: dense fp16 scores + per-query guard + exact re-score of the few surviving rows
     const bool use_dense = !use_scan && h->scan_ok && h->force_path != 1 && h->ksteps <= kMaxKSteps &&
-                           h->Npad <= 8192 && nq >= 64 && k <= 1024 && (int64_t)k * 2 <= h->N;
+                           h->Npad <= kDenseMaxRows && nq >= 64 && k <= 1024 && (int64_t)k * 2 <= h->N &&
+                           !h->tile16 && (h->Npad + std::max(128, 2 * k + 64)) * 4 <= 65536;   // scores + candidates in LDS
     if (use_dense) {
         const int64_t Qp = (nq + 63) / 64 * 64;
         const int cand_cap = std::max(128, 2 * k + 64);
