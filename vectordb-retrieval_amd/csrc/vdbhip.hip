@@ -265,6 +265,33 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     return g;
 }
 
+// Direct-bin geometry (32-row-tile layout only): when N/256 superbins cannot outnumber k four to one, level-1 bins
+// of 8 or 4 tiles (128 / 64 rows) serve as the superbins themselves (SelectArgs.direct_bt); the chunking then only
+// shapes the grid.  Returns the tiles per bin, 0 if not applicable.
+int scan_geometry_direct(const vdb_index_s *h, int k, ScanGeom &g) {
+    if (h->tile16) return 0;
+    const int64_t nspans = h->Npad / kSpanRows;
+    if (nspans < 8) return 0;
+    for (int bt : {8, 4}) {
+        const int64_t nb = nspans * 2 * (kTilesPerSpan / bt);
+        if (nb >= 4 * (int64_t)k && nb <= 1024) {
+            g = ScanGeom{};
+            g.nspans = nspans;
+            int64_t nchunks = (nspans + 15) / 16;
+            if (nchunks >= 16) nchunks = (nchunks + 7) / 8 * 8;
+            nchunks = std::min<int64_t>(nchunks, nspans);
+            g.nchunks = (int)nchunks;
+            g.spc = (int)(nspans / nchunks);
+            g.rem = (int)(nspans - (int64_t)g.spc * nchunks);
+            g.vpl = 1;
+            while (g.vpl * 64 < nb) g.vpl *= 2;
+            g.ok = true;
+            return bt;
+        }
+    }
+    return 0;
+}
+
 // scan kernel variants: {waves per workgroup, tiles per LDS stage, waves per SIMD}.  Variant 0 is the
 // production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
 // ablations of variant 0 and return wrong results).
@@ -274,7 +301,14 @@ constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {4, 4, 2}, {8, 4, 2}, {8, 4,
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
 template <int KSTEPS>
-void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
+void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16) {
+    if (bt != 16) {            // direct-bin mode: finer level-1 bins (8 or 4 tiles), production schedule only
+        sa.nqtiles = (int)(Qpad / 512);
+        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
+        if (bt == 8) scan_kernel<KSTEPS, 8, 4, 2, 0, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
+        else scan_kernel<KSTEPS, 8, 4, 2, 0, 4><<<dim3(grid), dim3(512), 0, st>>>(sa);
+        return;
+    }
     const ScanVariant v = kScanVariants[variant];
     sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
     const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
@@ -292,7 +326,7 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     }
 }
 
-void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st) {
+void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16) {
     if (h->ksteps > kMaxKSteps) {  // D > 128
         // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
         // option kloop_qgroup = query tiles per group of the block order (0 -> default)
@@ -339,9 +373,9 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
             else scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
         }
     } else if (h->ksteps == 4)
-        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st);
+        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st, bt);
     else
-        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st);
+        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st, bt);
     VDB_HIP(hipGetLastError());
 }
 
@@ -389,7 +423,11 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 
     ScanGeom g;
     bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
-    if (use_scan) g = scan_geometry(h, k);
+    int direct_bt = 0;
+    if (use_scan) {
+        g = scan_geometry(h, k);
+        if (!g.ok) direct_bt = scan_geometry_direct(h, k, g);
+    }
     // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
     //  needs ~0.07 ms per query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
     // Between the dense small-corpus path (<= 8192 rows) and 32768 rows the scan pays off once the batch carries
@@ -552,7 +590,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     // ---- MFMA scan path ------------------------------------------------------------------------------
     const int64_t Qpad = (nq + 511) / 512 * 512;
     const int G = h->tile16 ? 4 : 2;
-    const int64_t nbins = g.nspans * G, nsb = (int64_t)g.nchunks * G;
+    const int64_t nbins = g.nspans * G * (direct_bt ? kTilesPerSpan / direct_bt : 1), nsb = (int64_t)g.nchunks * G;
     const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
     const int rescan_cap = std::max(16, k / 2 + 8);
     ws.info.reserve(sizeof(QueryBatchInfo));
@@ -610,7 +648,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         h->dbg_words = nblocks * 8 * 8;
     }
     timing_mark(h, tslot, 0, st);
-    launch_scan(h, sa, g.nchunks, Qpad, st);
+    launch_scan(h, sa, g.nchunks, Qpad, st, direct_bt ? direct_bt : 16);
     timing_mark(h, tslot, 1, st);
 
     SelectArgs se{};
@@ -630,6 +668,11 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.nchunks = g.nchunks;
     se.k = k;
     se.groups = G;
+    se.direct_bt = direct_bt;
+    if (direct_bt) {        // the level-1 bins are the superbins
+        se.sb_m1 = sa.bin_m1;
+        se.sb_m2 = sa.bin_m2;
+    }
     se.cand_cap = cand_cap;
     se.rescan_cap = rescan_cap;
     se.cand_rows = ws.cand.as<int32_t>();
@@ -640,7 +683,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
     const int nsb_i = G * g.nchunks;
-    if (nsb_i <= 256 && h->select_variant == 0) {  // multi-lane form: 16 lanes per query, 4 queries per wave
+    if (nsb_i <= 256 && h->select_variant == 0 && !direct_bt) {  // multi-lane form: 16 lanes per query, 4 queries per wave
         const unsigned sgrid = (unsigned)((nq + 15) / 16);
         if (nsb_i <= 64)
             select_kernel_v2<4, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
