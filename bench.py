@@ -145,6 +145,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything native libraries print on file descriptor 1 while
+    # the job runs (the pool exports NCCL_DEBUG=VERSION, so RCCL prints a five-line banner there) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,10 +272,13 @@ def main() -> None:
         base, recall = cpu_baseline(X, Q, k, metric, gpu_ids)
         out["cpu_baseline"] = base
         out["recall@10_vs_cpu_oracle_sample"] = round(recall, 6)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
