@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QPS of the exact k-NN hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|gaussian1m|glove1.2m|marco2m|marco12.5m|smoke]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|gaussian1m|glove1.2m|marco2m|marco12.5m|gauss50m|smoke]
 
 A "step" is one pass of the hot path over one 10 000-query batch already resident in HBM:
 libvdbhip's device pipeline (query prep -> fp16 MFMA scan + bin select -> exact float64 refine), and for
@@ -46,6 +46,7 @@ WORKLOADS = {
     # BASELINE configs[4] per-GPU shard (100M x 768 over 8 GPUs): rows generated ON DEVICE in fixed 500k-row
     # blocks seeded by the global block number, so the data do not depend on the number of ranks
     "marco12.5m": (12_500_000, 768, 10_000, 10, "ip", "device_gaussian"),
+    "gauss50m": (50_000_000, 128, 10_000, 10, "l2", "device_gaussian"),     # capacity check of the flat D <= 128 path
     "smoke": (10_000, 128, 100, 10, "l2", "random_reference"),
 }
 DEVICE_BLOCK_ROWS = 500_000
