@@ -152,7 +152,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
 int vdb_set_option(vdb_handle h, const char *key, double value);
 
 /* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */
-/* raw scan scores (scaled units) for queries x rows [row0,row0+nrows): out (nq, nrows) float32,
+/* raw scan scores (scaled units) for queries x rows [row0,row0+nrows), any D <= 4096: out (nq, nrows) float32,
  * together with the per-query bound eps (nq) and the scale cs so that score/cs ~ (||x||^2 - 2 q.x) or -q.x */
 int vdb_debug_scan_scores(vdb_handle h, const float *q_host, int64_t nq, int64_t row0, int64_t nrows,
                           float *scores_host, float *eps_host, double *cscale);

@@ -428,3 +428,21 @@ def test_p16_panel_layout_for_small_dims_is_exact(vdb, oracle, d, metric, kind):
     err = np.abs(scores.astype(np.float64) / cs - exact)
     assert np.all(err <= (eps.astype(np.float64) / cs)[:, None])
     idx.close()
+
+
+@pytest.mark.parametrize("d,metric", [(200, "l2"), (384, "ip"), (768, "l2")])
+def test_fp16_scan_error_bound_holds_on_the_kloop_layout(vdb, d, metric):
+    """Same premise as above for D > 128 (p16 panels, K-loop scan): |raw MFMA score - exact| <= eps for every pair."""
+    X, Q = _make(3000, d, 40, "gauss", 31 + d)
+    X[::7] *= 3.0                       # uneven norms
+    idx = vdb.FlatIndex(d, metric, 0)
+    idx.add(X)
+    scores, eps, cs = idx.debug_scan_scores(Q, 100, 2500)
+    X64, Q64 = X[100:2600].astype(np.float64), Q.astype(np.float64)
+    dots = Q64 @ X64.T
+    exact = ((X64 * X64).sum(1)[None, :] - 2.0 * dots) if metric == "l2" else -dots
+    err = np.abs(scores.astype(np.float64) / cs - exact)
+    bound = (eps.astype(np.float64) / cs)[:, None]
+    assert np.all(err <= bound), (d, metric, float(err.max()), float(bound.min()))
+    assert float(err.max()) > 0.0       # (the hook really returns fp16-scan values, not exact ones)
+    idx.close()
