@@ -147,6 +147,8 @@ CASES = [
     (20000, 64, 300, 50, "l2", "gauss"),    # large k on a mid-size corpus: 64-row bins as superbins (direct mode)
     (40000, 128, 200, 100, "ip", "gauss"),
     (100000, 100, 120, 100, "l2", "sift"),  # 128-row bins as superbins
+    (100000, 384, 60, 200, "ip", "gauss"),  # same on the K-loop path: MS MARCO-subset shape, ground-truth k
+    (50000, 200, 90, 64, "l2", "gauss"),
     (40000, 128, 200, 10, "l2", "gauss"),   # MFMA scan path
     (40000, 128, 200, 10, "ip", "gauss"),
     (50000, 50, 130, 10, "ip", "glove"),
@@ -189,7 +191,7 @@ def test_flat_index_bit_exact_vs_oracle(vdb, oracle, n, d, nq, k, metric, kind):
     big_batch = npad > 8192 and nq * n >= 4_000_000
     std_geom = npad // 256 >= 16 and npad // 256 >= 4 * k
     # direct-bin mode (32-row-tile layout): 128- or 64-row bins as superbins when N/256 of them are too few for k
-    direct = d <= 128 and npad // 512 >= 8 and any(4 * k <= (npad // 512) * 2 * (16 // bt) <= 1024 for bt in (8, 4))
+    direct = npad // 256 >= 16 and any(4 * k <= (npad // 256) * (256 // rows) <= 2048 for rows in (128, 64))
     if (n >= 32768 or big_batch) and k <= 1024 and (std_geom or direct):
         assert st["last_path_name"] == "mfma_scan", st
         assert st["last_fallback_queries"] == 0, st

@@ -608,9 +608,9 @@ struct SelectArgs {
     int64_t nq, Qpad, nspans, N;
     int spans_per_chunk, chunk_rem, nchunks, k;
     int groups;                  // bins per span: 2 (32-row tiles, 512-row spans) or 4 (p16: 16-row tiles, 1024-row spans)
-    int direct_bt;               // 0, or: the level-1 bins (direct_bt tiles = 16*direct_bt rows each, 32-row-tile layout)
-                                 // ARE the superbins -- sb_m1 / sb_m2 alias bin_m1 / bin_m2, sb_span is unused (large k on
-                                 // mid-size corpora: N/256 superbins would be fewer than 4k)
+    int direct_rows;             // 0, or: the level-1 bins (direct_rows = 128 or 64 consecutive rows each) ARE the
+                                 // superbins -- sb_m1 / sb_m2 alias bin_m1 / bin_m2, sb_span is unused (large k on
+                                 // mid-size corpora, where N/256 superbins would be fewer than 4k)
     int cand_cap, rescan_cap;
     int32_t *cand_rows;          // [nq][cand_cap]
     int32_t *rescan_rows;        // [nq][rescan_cap]
@@ -626,8 +626,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (q >= a.nq) return;
-    const int dbps = a.direct_bt ? kTilesPerSpan / a.direct_bt : 0;      // direct mode: bins per (span, lane half)
-    const int nsb = a.direct_bt ? (int)a.nspans * a.groups * dbps : a.nchunks * a.groups;
+    const int dbps = a.direct_rows ? kBinRows / a.direct_rows : 0;       // direct mode: bins per (span, lane group)
+    const int nsb = a.direct_rows ? (int)a.nspans * a.groups * dbps : a.nchunks * a.groups;
     unsigned v[VPL];
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
@@ -663,10 +663,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             int sspan = 0;
             if (active) {
                 sm2 = a.sb_m2[(size_t)s * a.Qpad + q];
-                if (!a.direct_bt) sspan = a.sb_span[(size_t)s * a.Qpad + q];
+                if (!a.direct_rows) sspan = a.sb_span[(size_t)s * a.Qpad + q];
             }
-            if (a.direct_bt) {   // the superbin is a bin of 16*direct_bt consecutive rows: candidate quad or re-scan, no walk
-                const int row0 = (s / dbps) * kBinRows + (s % dbps) * (16 * a.direct_bt);
+            if (a.direct_rows) {   // the superbin is a bin of direct_rows consecutive rows: candidate quad or re-scan, no walk
+                const int row0 = (s / dbps) * kBinRows + (s % dbps) * a.direct_rows;
                 const bool single = active && !(sm2 <= that), deep = active && !single;
                 const unsigned long long smask = __ballot(single), rmask = __ballot(deep);
                 if (single) {
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     const int pos = nres + __popcll(rmask & lt_mask);
                     if (pos < a.rescan_cap) {
                         rr[2 * pos] = row0;
-                        rr[2 * pos + 1] = row0 + 16 * a.direct_bt;   // (clipped to N by the refine kernel)
+                        rr[2 * pos + 1] = row0 + a.direct_rows;   // (clipped to N by the refine kernel)
                     }
                 }
                 ncand += __popcll(smask);

@@ -214,10 +214,12 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(ScanArgs a) {
 // A fragments are software pipelined one group (4 ds_read_b128 -> 16 MFMAs) ahead; 4 groups per K-step:
 // (k-step 0, tiles 0-3), (0, 4-7), (1, 0-3), (1, 4-7).  Eight passes complete the four 256-row bins of a span.
 // BS / ring / barrier placement / ABL builds: see scan_kloop_kernel.
-template <int ABL, int BS>
+// FP: passes per level-1 bin (8: the 256-row bins (span, g); 4 / 2: 128- / 64-row bins for the direct-bin select).
+template <int ABL, int BS, int FP = 8>
 __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
     constexpr int NWAVES = 8, RING = 2 * BS, HT = 8, CB = 4;
     constexpr int PPS = kTilesPerSpan16 / HT;               // passes per span (8)
+    static_assert(PPS % FP == 0, "bins must tile the span");
     constexpr int kStageVec = HT * 2 * 64;                  // 16-byte vectors per K-step stage (16 KiB)
     __shared__ __attribute__((aligned(16))) unsigned char smem[RING * kStageVec * 16];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
         }
 #pragma unroll
         for (int t = 0; t < (ABL == 4 ? 0 : HT); ++t) {
-            const unsigned id = (unsigned)(slice * HT + t);     // tile number inside the span = quad number in the bin
+            const unsigned id = (unsigned)((slice % FP) * HT + t);   // quad number inside the level-1 bin
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
@@ -359,10 +361,10 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
                 m1[cb] = fast_min(m1[cb], v, NEG_INF);
             }
         }
-        if (slice == PPS - 1) {
+        if (slice % FP == FP - 1) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const size_t o = (size_t)(span * 4 + g) * a.Qpad + q0 + cb * 16 + (lane & 15);
+                const size_t o = (size_t)((span * 4 + g) * (PPS / FP) + slice / FP) * a.Qpad + q0 + cb * 16 + (lane & 15);
                 a.bin_m1[o] = m1[cb];
                 a.bin_m2[o] = m2[cb];
                 M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);

@@ -265,28 +265,30 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     return g;
 }
 
-// Direct-bin geometry (32-row-tile layout only): when N/256 superbins cannot outnumber k four to one, level-1 bins
-// of 8 or 4 tiles (128 / 64 rows) serve as the superbins themselves (SelectArgs.direct_bt); the chunking then only
-// shapes the grid.  Returns the tiles per bin, 0 if not applicable.
+// Direct-bin geometry: when N/256 superbins cannot outnumber k four to one, level-1 bins of 128 or 64 rows serve as
+// the superbins themselves (SelectArgs.direct_rows, up to 2048 of them); the chunking then only shapes the grid.
+// Returns the rows per bin, 0 if not applicable.
 int scan_geometry_direct(const vdb_index_s *h, int k, ScanGeom &g) {
-    if (h->tile16) return 0;
-    const int64_t nspans = h->Npad / kSpanRows;
-    if (nspans < 8) return 0;
-    for (int bt : {8, 4}) {
-        const int64_t nb = nspans * 2 * (kTilesPerSpan / bt);
-        if (nb >= 4 * (int64_t)k && nb <= 1024) {
+    const int G = h->tile16 ? 4 : 2;
+    // kernels with the finer bins: scan_kernel<.., BT> (32-row tiles, D <= 128) and scan16_kloop_kernel<.., FP> (p16, D > 128)
+    if (h->tile16 != (h->ksteps > kMaxKSteps)) return 0;
+    const int64_t nspans = h->Npad / (G * kBinRows);
+    if (nspans * G < 16) return 0;
+    for (int rows : {128, 64}) {
+        const int64_t nb = nspans * G * (kBinRows / rows);
+        if (nb >= 4 * (int64_t)k && nb <= 2048) {
             g = ScanGeom{};
             g.nspans = nspans;
-            int64_t nchunks = (nspans + 15) / 16;
+            int64_t nchunks = (nspans * G + 31) / 32;                 // ~8192 rows per chunk
             if (nchunks >= 16) nchunks = (nchunks + 7) / 8 * 8;
-            nchunks = std::min<int64_t>(nchunks, nspans);
+            nchunks = std::max<int64_t>(1, std::min<int64_t>(nchunks, nspans));
             g.nchunks = (int)nchunks;
             g.spc = (int)(nspans / nchunks);
             g.rem = (int)(nspans - (int64_t)g.spc * nchunks);
             g.vpl = 1;
             while (g.vpl * 64 < nb) g.vpl *= 2;
             g.ok = true;
-            return bt;
+            return rows;
         }
     }
     return 0;
@@ -326,7 +328,8 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     }
 }
 
-void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16) {
+void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int direct_rows = 0) {
+    const int bt = direct_rows ? direct_rows / 16 : 16;       // 32-row-tile layout: tiles per level-1 bin
     if (h->ksteps > kMaxKSteps) {  // D > 128
         // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
         // option kloop_qgroup = query tiles per group of the block order (0 -> default)
@@ -337,6 +340,12 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
         const unsigned ngroups = (unsigned)((sa.nqtiles + qgroup - 1) / qgroup);
         const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * ngroups * (unsigned)qgroup;
         const ScanKloopExtra ex{h->ksteps, qgroup};
+        if (h->tile16 && direct_rows) {      // finer level-1 bins (production schedule only)
+            if (direct_rows == 128) scan16_kloop_kernel<0, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
+            else scan16_kloop_kernel<0, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
+            VDB_HIP(hipGetLastError());
+            return;
+        }
         if (h->tile16) {
             switch (h->scan_variant) {
                 case 2: scan16_kloop_kernel<0, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
@@ -423,10 +432,10 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 
     ScanGeom g;
     bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
-    int direct_bt = 0;
+    int direct_rows = 0;
     if (use_scan) {
         g = scan_geometry(h, k);
-        if (!g.ok) direct_bt = scan_geometry_direct(h, k, g);
+        if (!g.ok) direct_rows = scan_geometry_direct(h, k, g);
     }
     // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
     //  needs ~0.07 ms per query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
@@ -590,7 +599,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     // ---- MFMA scan path ------------------------------------------------------------------------------
     const int64_t Qpad = (nq + 511) / 512 * 512;
     const int G = h->tile16 ? 4 : 2;
-    const int64_t nbins = g.nspans * G * (direct_bt ? kTilesPerSpan / direct_bt : 1), nsb = (int64_t)g.nchunks * G;
+    const int64_t nbins = g.nspans * G * (direct_rows ? kBinRows / direct_rows : 1), nsb = (int64_t)g.nchunks * G;
     const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
     const int rescan_cap = std::max(16, k / 2 + 8);
     ws.info.reserve(sizeof(QueryBatchInfo));
@@ -648,7 +657,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         h->dbg_words = nblocks * 8 * 8;
     }
     timing_mark(h, tslot, 0, st);
-    launch_scan(h, sa, g.nchunks, Qpad, st, direct_bt ? direct_bt : 16);
+    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows);
     timing_mark(h, tslot, 1, st);
 
     SelectArgs se{};
@@ -668,8 +677,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.nchunks = g.nchunks;
     se.k = k;
     se.groups = G;
-    se.direct_bt = direct_bt;
-    if (direct_bt) {        // the level-1 bins are the superbins
+    se.direct_rows = direct_rows;
+    if (direct_rows) {        // the level-1 bins are the superbins
         se.sb_m1 = sa.bin_m1;
         se.sb_m2 = sa.bin_m2;
     }
@@ -683,7 +692,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
     const int nsb_i = G * g.nchunks;
-    if (nsb_i <= 256 && h->select_variant == 0 && !direct_bt) {  // multi-lane form: 16 lanes per query, 4 queries per wave
+    if (nsb_i <= 256 && h->select_variant == 0 && !direct_rows) {  // multi-lane form: 16 lanes per query, 4 queries per wave
         const unsigned sgrid = (unsigned)((nq + 15) / 16);
         if (nsb_i <= 64)
             select_kernel_v2<4, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
@@ -697,7 +706,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             case 2: launch_select<2>(se, st); break;
             case 4: launch_select<4>(se, st); break;
             case 8: launch_select<8>(se, st); break;
-            default: launch_select<16>(se, st); break;
+            case 16: launch_select<16>(se, st); break;
+            default: launch_select<32>(se, st); break;
         }
     }
     VDB_HIP(hipGetLastError());
