@@ -249,6 +249,7 @@ struct IvfSelectArgs {
     const int32_t *slot_off, *list_item0, *item_bin0, *list_pspan0, *span_row0, *span_valid;
     int64_t nq;
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
+    int probe_cap;                // nprobe rounded up to 64: size of the per-probe LDS arrays
     int bt, bps;                  // tiles per bin, bins per (span, lane half)
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
@@ -266,12 +267,14 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 2 + wave));
     if (q >= a.nq) return;
-    // per wave: vals[max_entries] | p_off[kIvfMaxProbes+32] | p_base lo/hi [2*kIvfMaxProbes] | p_list[kIvfMaxProbes]
-    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.max_entries + 4 * kIvfMaxProbes + 64);
+    // per wave: vals[max_entries] | p_off[probe_cap+32] | p_base lo/hi [2*probe_cap] | p_list[probe_cap] -- sized by
+    // the launch (what this nprobe and the longest list can need), not by the compile-time maxima: the LDS footprint
+    // is what limits how many queries a CU works on at once
+    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.max_entries + 4 * a.probe_cap + 64);
     int *p_off = reinterpret_cast<int *>(vals + a.max_entries);
-    unsigned *p_base_lo = reinterpret_cast<unsigned *>(p_off + kIvfMaxProbes + 32);
-    unsigned *p_base_hi = p_base_lo + kIvfMaxProbes;
-    int *p_list = reinterpret_cast<int *>(p_base_hi + kIvfMaxProbes);
+    unsigned *p_base_lo = reinterpret_cast<unsigned *>(p_off + a.probe_cap + 32);
+    unsigned *p_base_hi = p_base_lo + a.probe_cap;
+    int *p_list = reinterpret_cast<int *>(p_base_hi + a.probe_cap);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool fb = a.plan->overflow || a.info->force_fallback || a.nprobe > kIvfMaxProbes;
     int E = 0;
