@@ -27,7 +27,7 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
     const float4 *qv = reinterpret_cast<const float4 *>(q);
     double acc = 0.0;
     if (metric == 0) {
-#pragma unroll 4
+#pragma unroll 16
         for (int i = 0; i < D4 / 4; ++i) {
             const float4 a = xv[i];
             const float4 b = qv[i];
@@ -39,7 +39,7 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
         }
         return sortable_u64(acc);
     } else {
-#pragma unroll 4
+#pragma unroll 16
         for (int i = 0; i < D4 / 4; ++i) {
             const float4 a = xv[i];
             const float4 b = qv[i];
