@@ -97,6 +97,59 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const half8 *A, const half
     out[blockIdx.x * 512 + tid] = sum + m1[0] + m1[1] + m1[2] + m1[3] + m2[0] + m2[1] + m2[2] + m2[3];
 }
 
+// 32x32x16 with the select interleaved INTO the MFMA stream by sched_group_barrier: per tile, phase A issues the 8
+// MFMAs of column block 0 while retiring block 1 of the previous tile (3 VALU per MFMA), phase B issues block 1's MFMAs
+// while retiring block 0 of this tile and requesting the next tile's fragments (1 ds_read per MFMA).
+__global__ __launch_bounds__(512, 2) void fused_kernel(const half8 *A, const half8 *B, float *out, int iters) {
+    __shared__ half8 lds[kTiles * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < kTiles * 8 * 64; i += 512) lds[i] = A[i];
+    half8 b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = B[(wave * 16 + i) * 64 + lane];
+    __syncthreads();
+    float m1[2] = {1e30f, 1e30f}, m2[2] = {1e30f, 1e30f};
+    half8 fr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) fr[ks] = lds[ks * 64 + lane];
+    float16v acc0 = {0}, acc1 = {0};
+    const float16v zero = {0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int t = 0; t < kTiles; ++t) {
+            // ---- phase A: MFMA block 0 (tile t)  ||  select block 1 (tile t-1)
+            float16v prev1 = acc1;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks], b[ks], ks == 0 ? zero : acc0, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) quad(prev1[4 * g], prev1[4 * g + 1], prev1[4 * g + 2], prev1[4 * g + 3], t * 4 + g, m1[1], m2[1]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase B: MFMA block 1 (tile t)  ||  select block 0 (tile t)  ||  fragments of tile t+1
+            const half8 *an = lds + ((t + 1) % kTiles) * 8 * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks], b[8 + ks], ks == 0 ? zero : acc1, 0, 0, 0);
+                fr[ks] = an[ks * 64];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) quad(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3], t * 4 + g, m1[0], m2[0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    out[blockIdx.x * 512 + tid] = m1[0] + m1[1] + m2[0] + m2[1] + acc1[0];
+}
+
 int main(int argc, char **argv) {
     const int integer_data = argc > 1 ? atoi(argv[1]) : 0;
     const int nblk = 256 * 4, iters = 600;
@@ -114,15 +167,16 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flops = (double)nblk * 8 * iters * kTiles * 16 * 32768.0;   // per wave and unit: 16 MFMA 32x32x16
     for (int round = 0; round < 3; ++round)
-      for (int epi = 0; epi < 3; ++epi)
+      for (int epi = 0; epi < 4; ++epi)      // 0 bare, 1 select, 2 select + bias init, 3 select interleaved by sched_group_barrier
         for (int shape : {32, 16}) {
-            if (epi == 2 && shape == 16) continue;   // (bias variant: 32x32 only)
+            if (epi >= 2 && shape == 16) continue;   // (variants 2, 3: 32x32 only)
             float best = 1e30f;
             for (int rep = 0; rep < 5; ++rep) {
                 CK(hipEventRecord(e0));
                 if (shape == 32 && !epi) loop_kernel<32, false><<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (shape == 32 && epi == 1) loop_kernel<32, true><<<nblk, 512>>>(dA, dB, dO, iters);
-                else if (shape == 32) loop_kernel<32, true, true><<<nblk, 512>>>(dA, dB, dO, iters);
+                else if (shape == 32 && epi == 2) loop_kernel<32, true, true><<<nblk, 512>>>(dA, dB, dO, iters);
+                else if (shape == 32) fused_kernel<<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (!epi) loop_kernel<16, false><<<nblk, 512>>>(dA, dB, dO, iters);
                 else loop_kernel<16, true><<<nblk, 512>>>(dA, dB, dO, iters);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
