@@ -150,6 +150,45 @@ __global__ __launch_bounds__(512, 2) void fused_kernel(const half8 *A, const hal
     out[blockIdx.x * 512 + tid] = m1[0] + m1[1] + m2[0] + m2[1] + acc1[0];
 }
 
+// 32x32x16, FOUR column blocks per wave (128 queries, B = 128 VGPRs), one wave per SIMD (4 waves per workgroup):
+// every A fragment read from LDS feeds 4 MFMAs instead of 2 -- how much of the power budget do the LDS reads take?
+template <bool EPI>
+__global__ __launch_bounds__(256, 1) void wide_kernel(const half8 *A, const half8 *B, float *out, int iters) {
+    __shared__ half8 lds[kTiles * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < kTiles * 8 * 64; i += 256) lds[i] = A[i];
+    half8 b[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) b[i] = B[((wave * 32 + i) % 128) * 64 + lane];
+    __syncthreads();
+    float sum = 0.f;
+    float m1[4] = {1e30f, 1e30f, 1e30f, 1e30f}, m2[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int t = 0; t < kTiles; ++t) {
+            float16v acc[4] = {{0}, {0}, {0}, {0}};
+            const half8 *a = lds + t * 8 * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const half8 f = a[ks * 64];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, b[cb * 8 + ks], acc[cb], 0, 0, 0);
+            }
+            if (EPI) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        quad(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3], t * 4 + g, m1[cb], m2[cb]);
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) sum += acc[cb][0];
+            }
+        }
+    }
+    out[blockIdx.x * 256 + tid] = sum + m1[0] + m1[1] + m1[2] + m1[3] + m2[0] + m2[1] + m2[2] + m2[3];
+}
+
 int main(int argc, char **argv) {
     const int integer_data = argc > 1 ? atoi(argv[1]) : 0;
     const int nblk = 256 * 4, iters = 600;
@@ -168,12 +207,14 @@ int main(int argc, char **argv) {
     const double flops = (double)nblk * 8 * iters * kTiles * 16 * 32768.0;   // per wave and unit: 16 MFMA 32x32x16
     for (int round = 0; round < 3; ++round)
       for (int epi = 0; epi < 4; ++epi)      // 0 bare, 1 select, 2 select + bias init, 3 select interleaved by sched_group_barrier
-        for (int shape : {32, 16}) {
-            if (epi >= 2 && shape == 16) continue;   // (variants 2, 3: 32x32 only)
+        for (int shape : {32, 16, 64}) {          // 64 = 32x32x16 with 4 column blocks per wave, 1 wave per SIMD
+            if (epi >= 2 && shape != 32) continue;   // (variants 2, 3: 32x32 only)
             float best = 1e30f;
             for (int rep = 0; rep < 5; ++rep) {
                 CK(hipEventRecord(e0));
-                if (shape == 32 && !epi) loop_kernel<32, false><<<nblk, 512>>>(dA, dB, dO, iters);
+                if (shape == 64 && !epi) wide_kernel<false><<<nblk, 256>>>(dA, dB, dO, iters);
+                else if (shape == 64) wide_kernel<true><<<nblk, 256>>>(dA, dB, dO, iters);
+                else if (shape == 32 && !epi) loop_kernel<32, false><<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (shape == 32 && epi == 1) loop_kernel<32, true><<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (shape == 32 && epi == 2) loop_kernel<32, true, true><<<nblk, 512>>>(dA, dB, dO, iters);
                 else if (shape == 32) fused_kernel<<<nblk, 512>>>(dA, dB, dO, iters);
