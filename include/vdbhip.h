@@ -146,7 +146,8 @@ int vdb_ivf_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, 
 
 /* ---- introspection / tuning ---------------------------------------------------------------- */
 int vdb_stats(vdb_handle h, vdb_stats_t *out);
-/* options: "force_path" (0 auto, 1 exact kernels only, 2 MFMA scan whenever legal), "timing" (1: (re)start
+/* options: "force_path" (0 auto, 1 exact kernels only, 2 MFMA scan whenever legal, 3 exact kernels in their
+ * one-query-per-wave form), "timing" (1: (re)start
  * recording HIP-event times of every search, averaged by vdb_stats), "list_cap" (work-list capacity per query),
  * tuning knobs used by scripts/: "scan_variant", "select_variant", "spans_per_chunk", "kloop_qgroup", and
  * "panel_layout" (0 auto: 16-row-tile panels for D > 128; 1: 32-row tiles for every D; 2: 16-row tiles for every D;

@@ -52,6 +52,39 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
     }
 }
 
+// QB keys of ONE row against QB queries: the row is fetched once; every query keeps its own sequential chain, so each
+// key is bit-identical to exact_key().
+template <int QB>
+__device__ __forceinline__ void exact_keys(const float *__restrict__ x, const float *const (&q)[QB], int D4, int metric,
+                                           uint64_t (&out)[QB]) {
+    const float4 *xv = reinterpret_cast<const float4 *>(x);
+    double acc[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) acc[j] = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < D4 / 4; ++i) {
+        const float4 a = xv[i];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const float4 b = reinterpret_cast<const float4 *>(q[j])[i];
+            if (metric == 0) {
+                double t;
+                t = (double)a.x - (double)b.x; acc[j] = fma(t, t, acc[j]);
+                t = (double)a.y - (double)b.y; acc[j] = fma(t, t, acc[j]);
+                t = (double)a.z - (double)b.z; acc[j] = fma(t, t, acc[j]);
+                t = (double)a.w - (double)b.w; acc[j] = fma(t, t, acc[j]);
+            } else {
+                acc[j] = fma((double)b.x, (double)a.x, acc[j]);
+                acc[j] = fma((double)b.y, (double)a.y, acc[j]);
+                acc[j] = fma((double)b.z, (double)a.z, acc[j]);
+                acc[j] = fma((double)b.w, (double)a.w, acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) out[j] = sortable_u64(metric == 0 ? acc[j] : -acc[j]);
+}
+
 template <int KPL>
 __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon &c, const float *qptr, int64_t row0,
                                           int64_t row1) {
@@ -208,6 +241,60 @@ __global__ __launch_bounds__(256) void refine_full_kernel(RefineFullArgs a) {
         } else {
             const size_t o = (size_t)u * a.c.k;
             write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.pkeys + o, a.pids + o);
+        }
+    }
+}
+
+// Query-blocked form of the exhaustive scan: one wave owns QB consecutive slots and one row range, fetches every row
+// ONCE and scores it against the QB queries (the single-query form re-reads the whole corpus per query and runs at the
+// HBM roofline: 512 MB per query per 1M x 128 rows).  Same outputs and layouts as refine_full_kernel.
+template <int KPL, int QB>
+__global__ __launch_bounds__(256) void refine_full_blocked_kernel(RefineFullArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves_total = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
+    const int64_t groups = (count + QB - 1) / QB;
+    const int64_t units = groups * a.S;
+    for (int64_t u = wave0; u < units; u += waves_total) {
+        const int64_t grp = u / a.S;
+        const int split = (int)(u - grp * a.S);
+        int64_t slot[QB], q[QB];
+        const float *qptr[QB];
+        WaveTopK<KPL> tk[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            slot[j] = grp * QB + j;
+            const int64_t sj = slot[j] < count ? slot[j] : count - 1;      // (padding slots re-score the last query)
+            q[j] = a.qlist ? (int64_t)a.qlist[sj] : sj;
+            qptr[j] = a.c.Q + (size_t)q[j] * a.c.D4;
+            tk[j].init(a.c.k);
+        }
+        const int64_t r0 = (int64_t)split * a.rows_per_split;
+        int64_t r1 = r0 + a.rows_per_split;
+        if (r1 > a.c.N) r1 = a.c.N;
+        for (int64_t base = r0; base < r1; base += 64) {
+            const int64_t row = base + lane;
+            const bool valid = row < r1;
+            uint64_t key[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) key[j] = ~0ull;
+            if (valid) exact_keys<QB>(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric, key);
+            const int64_t id = a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row;
+#pragma unroll
+            for (int j = 0; j < QB; ++j) tk[j].offer(key[j], id, valid);
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            if (slot[j] < count) {
+                if (a.D) {
+                    const size_t o = (size_t)q[j] * a.c.k;
+                    write_topk<KPL>(tk[j], a.c.metric, a.D + o, a.I + o, nullptr, nullptr);
+                } else {
+                    const size_t o = (size_t)(slot[j] * a.S + split) * a.c.k;
+                    write_topk<KPL>(tk[j], a.c.metric, nullptr, nullptr, a.pkeys + o, a.pids + o);
+                }
+            }
         }
     }
 }

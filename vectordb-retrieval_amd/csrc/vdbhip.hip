@@ -146,6 +146,18 @@ void launch_refine_full(const RefineFullArgs &a, int64_t max_units, hipStream_t 
     VDB_HIP(hipGetLastError());
 }
 
+// query-blocked exhaustive scan (4 queries per wave): max_units = ceil(count / 4) * S
+constexpr int kRefineQB = 4;
+void launch_refine_full_blocked(const RefineFullArgs &a, int64_t max_units, hipStream_t st) {
+    int64_t blocks = (max_units + 3) / 4;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 8192));
+    if (kpl_for(a.c.k) == 1)
+        refine_full_blocked_kernel<1, kRefineQB><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+    else
+        refine_full_blocked_kernel<2, kRefineQB><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+    VDB_HIP(hipGetLastError());
+}
+
 void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
     int64_t blocks = (max_slots + 3) / 4;
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 4096));
@@ -431,7 +443,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k, nullptr};
 
     ScanGeom g;
-    bool use_scan = h->scan_ok && h->force_path != 1 && k <= 1024;
+    const bool exact_only = h->force_path == 1 || h->force_path == 3;   // 3: also without query blocking (A/B runs)
+    bool use_scan = h->scan_ok && !exact_only && k <= 1024;
     int direct_rows = 0;
     if (use_scan) {
         g = scan_geometry(h, k);
@@ -453,7 +466,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     const long tslot = timing_begin(h, st);
 
     // small corpora: dense fp16 scores + per-query guard + exact re-score of the few surviving rows
-    const bool use_dense = !use_scan && h->scan_ok && h->force_path != 1 && h->ksteps <= kMaxKSteps &&
+    const bool use_dense = !use_scan && h->scan_ok && !exact_only && h->ksteps <= kMaxKSteps &&
                            h->Npad <= kDenseMaxRows && nq >= 64 && k <= 1024 && (int64_t)k * 2 <= h->N &&
                            !h->tile16 && (h->Npad + std::max(128, 2 * k + 64)) * 4 <= 65536;   // scores + candidates in LDS
     if (use_dense) {
@@ -549,32 +562,46 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     }
 
     if (!use_scan) {
-        // exhaustive exact scan, split over S waves per query
-        int64_t S = (8192 + nq - 1) / nq;
-        S = std::min<int64_t>(S, std::max<int64_t>(1, h->N / 1024));
+        // exhaustive exact scan, split over S waves per query (per group of 4 queries in the query-blocked form,
+        // which fetches every row once for the four: k <= 128, at least 4 queries)
+        // (it needs enough (group, split) units to fill the chip: small corpora and tiny batches keep the one-query form)
+        bool blocked = kpl_for(k) <= 2 && nq >= 2 * kRefineQB && h->force_path != 3;
+        if (blocked) {
+            const int64_t g4 = (nq + kRefineQB - 1) / kRefineQB;
+            const int64_t s4 = std::min<int64_t>((4096 + g4 - 1) / g4, std::max<int64_t>(1, h->N / 2048));
+            blocked = g4 * s4 >= 1024;
+        }
+        const int64_t ngroups = blocked ? (nq + kRefineQB - 1) / kRefineQB : nq;
+        auto launch_full = [&](const RefineFullArgs &fa) {
+            if (blocked) launch_refine_full_blocked(fa, ngroups * fa.S, st);
+            else launch_refine_full(fa, nq * fa.S, st);
+        };
+        int64_t S = ((blocked ? 4096 : 8192) + ngroups - 1) / ngroups;
+        // (a split is worth >= 1024 rows; the blocked form merges 4x the partial lists per unit, so its splits are larger)
+        S = std::min<int64_t>(S, std::max<int64_t>(1, h->N / (blocked ? 2048 : 1024)));
         const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
         S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
         RefineFullArgs fa{};
         fa.c = rc;
         fa.count = nq;
         fa.S = (int)S;
-        fa.rows_per_split = (h->N + S - 1) / S;
-        if (fa.rows_per_split < 1) fa.rows_per_split = 1;
+        fa.rows_per_split = ((h->N + S - 1) / S + 63) / 64 * 64;     // whole 64-row wave iterations
+        if (fa.rows_per_split < 64) fa.rows_per_split = 64;
         timing_mark(h, tslot, 0, st);
         if (S == 1 && D) {
             fa.D = D;
             fa.I = I;
-            launch_refine_full(fa, nq, st);
+            launch_full(fa);
         } else if (S == 1) {
             fa.pkeys = pk;
             fa.pids = pi;
-            launch_refine_full(fa, nq, st);
+            launch_full(fa);
         } else {
             ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
             ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
             fa.pkeys = ws.pkeys.as<double>();
             fa.pids = ws.pids.as<int64_t>();
-            launch_refine_full(fa, nq * S, st);
+            launch_full(fa);
             MergeArgs ma{};
             ma.pkeys = fa.pkeys;
             ma.pids = fa.pids;
@@ -1130,7 +1157,8 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         if (!key) throw Error(VDB_ERR_INVALID, "null option name");
         const std::string k(key);
         if (k == "force_path") {
-            if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "force_path must be 0, 1 or 2");
+            if (value != 0 && value != 1 && value != 2 && value != 3)
+                throw Error(VDB_ERR_INVALID, "force_path must be 0, 1, 2 or 3");
             h->force_path = (int)value;
         } else if (k == "timing") {  // (re)starts the recording window
             h->timing = value != 0;
