@@ -32,6 +32,16 @@ constexpr int kStageTiles = 4;      // tiles per LDS stage (128 MFMA rows)
 constexpr int kMaxKSteps = 8;       // register-resident query fragments: D <= 128
 constexpr float kPadBias = 1.0e38f; // accumulator init of padding rows (scan units): never selected
 
+// Search statistics (candidates, re-scans, fallback queries) are counted with global atomics by every query; on ONE
+// address 20k adds per batch cost ~80 us (same-line atomics serialise in L2).  The counters are therefore kept in
+// kStatShards replicas, each on a 128-byte line of its own, picked by the query number; the host sums them.
+constexpr int kStatShards = 32;
+constexpr int kStatStride = 16;   // unsigned long long per shard (= 128 bytes)
+__device__ __forceinline__ void stat_add(unsigned long long *counters, long long q, int idx, unsigned long long v) {
+    atomicAdd(&counters[(size_t)(q & (kStatShards - 1)) * kStatStride + idx], v);
+}
+constexpr size_t kSmallBytes = 64 + (size_t)kStatShards * kStatStride * 8;   // ws.small: fb_count + sharded counters
+
 struct IndexStats {       // filled on device by the corpus-prep kernels
     unsigned absmax_bits; // bits of max |x|
     unsigned maxnorm2_bits; // bits of max ||x||^2 (float)

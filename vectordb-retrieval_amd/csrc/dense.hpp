@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
                     a.pids ? a.pids + o : nullptr);
     if (lane == 0) {
         a.fallback[q] = 0;
-        atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
+        stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
     }
 }
 

@@ -391,10 +391,10 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         a.counts[2 * q + 1] = fb ? 0 : nres;
         a.fallback[q] = fb ? 1 : 0;
         if (fb) {
-            atomicAdd(&a.stat_counters[2], 1ull);
+            stat_add(a.stat_counters, q, 2, 1ull);
         } else {
-            atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
-            atomicAdd(&a.stat_counters[1], (unsigned long long)nres);
+            stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
+            stat_add(a.stat_counters, q, 1, (unsigned long long)nres);
         }
     }
 }

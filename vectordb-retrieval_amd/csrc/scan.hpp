@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             const int pos = atomicAdd(a.fb_count, 1);
             a.fb_list[pos] = (int)q;
         } else {
-            atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
-            atomicAdd(&a.stat_counters[1], (unsigned long long)nres);
+            stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
+            stat_add(a.stat_counters, q, 1, (unsigned long long)nres);
         }
     }
 }
@@ -760,13 +760,15 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 template <int V, int LPQ>
 __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     constexpr int QPW = 64 / LPQ;
-    __shared__ int s_cnt[4][QPW][2];
+    constexpr int kDeepCap = 48;                    // queued deep superbins per query (more -> exhaustive fallback)
+    __shared__ int s_cnt[4][QPW][3];
+    __shared__ int s_deep[4][QPW][kDeepCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = lane / LPQ, part = lane % LPQ;
     const int64_t q = ((int64_t)blockIdx.x * 4 + wave) * QPW + qi;   // < Qpad by construction of the grid
     const bool qvalid = q < a.nq;
     const int nsb = a.nchunks * a.groups;
-    if (part < 2) s_cnt[wave][qi][part] = 0;
+    if (part < 3) s_cnt[wave][qi][part] = 0;
     unsigned v[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -787,10 +789,11 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     const float that = tau + 2.0f * (qvalid ? a.eps[q] : 0.f);
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
     __syncthreads();  // counters zeroed
-    int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1];
+    int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1], *cnt_d = &s_cnt[wave][qi][2];
+    int *deep = &s_deep[wave][qi][0];
+    bool deep_overflow = false;
     if (qvalid && !force_fb) {
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
-        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
         // second minimum and span of every ACTIVE superbin, loaded up front so the latencies overlap
         float sm2v[V];
         int spanv[V];
@@ -812,35 +815,45 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
                     cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(m1));
-            } else {               // two or more interesting scores: walk the level-1 bins of this superbin
-                const int chunk = s / a.groups;
-                const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
-                int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
-                if (sp1 > a.nspans) sp1 = a.nspans;
-                for (int64_t spb = sp0; spb < sp1; spb += 8) {
-                  // (8 independent loads in flight: the bins of a chunk used to be fetched one dependent load at a time)
-                  float bm1v[8];
+            } else {               // two or more interesting scores: queue the superbin for the cooperative walk below
+                const int pos = atomicAdd(cnt_d, 1);
+                if (pos < kDeepCap) deep[pos] = s;
+            }
+        }
+    }
+    __syncthreads();
+    // Deep superbins: the LPQ lanes of a query walk the level-1 bins of one queued superbin TOGETHER (lane `part` takes
+    // spans part, part + LPQ, ...), so a superbin costs two dependent memory round trips however many spans its chunk
+    // has -- walking it inside the loop above serialised a wave on every lane that met one.
+    {
+        const int nd_q = (qvalid && !force_fb) ? *cnt_d : 0;
+        int nd_max = nd_q;                                   // loop count must be wave-uniform
 #pragma unroll
-                  for (int u = 0; u < 8; ++u)
-                      bm1v[u] = (spb + u < sp1) ? a.bin_m1[(size_t)((spb + u) * a.groups + hh) * a.Qpad + q] : __builtin_inff();
-#pragma unroll
-                  for (int u = 0; u < 8; ++u) {
-                    const int64_t sp = spb + u;
-                    const float bm1 = bm1v[u];
-                    if (!(bm1 <= that)) continue;
-                    const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
-                    if (a.bin_m2[o] <= that) {
-                        const int pos = atomicAdd(cnt_r, 1);
-                        if (pos < a.rescan_cap) {
-                            rr[2 * pos] = (int)((sp * a.groups + hh) * kBinRows);
-                            rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
-                        }
-                    } else {
-                        const int pos = atomicAdd(cnt_c, 1);
-                        if (pos < a.cand_cap)
-                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
+        for (int o = 1; o < 64; o <<= 1) nd_max = max(nd_max, __shfl_xor(nd_max, o));
+        if (nd_q > kDeepCap) deep_overflow = true;
+        int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
+        int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+        for (int d = 0; d < nd_max && d < kDeepCap; ++d) {
+            if (d >= nd_q) continue;
+            const int s = deep[d];
+            const int chunk = s / a.groups, hh = s % a.groups;
+            const int64_t sp0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+            int64_t sp1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
+            if (sp1 > a.nspans) sp1 = a.nspans;
+            for (int64_t sp = sp0 + part; sp < sp1; sp += LPQ) {
+                const size_t o = (size_t)(sp * a.groups + hh) * a.Qpad + q;
+                const float bm1 = a.bin_m1[o];
+                if (!(bm1 <= that)) continue;
+                if (a.bin_m2[o] <= that) {
+                    const int pos = atomicAdd(cnt_r, 1);
+                    if (pos < a.rescan_cap) {
+                        rr[2 * pos] = (int)((sp * a.groups + hh) * kBinRows);
+                        rr[2 * pos + 1] = rr[2 * pos] + kBinRows;   // (clipped to N by the refine kernel)
                     }
-                  }
+                } else {
+                    const int pos = atomicAdd(cnt_c, 1);
+                    if (pos < a.cand_cap)
+                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
                 }
             }
         }
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     __syncthreads();
     if (qvalid && part == 0) {
         const int ncand = *cnt_c, nres = *cnt_r;
-        const bool fb = force_fb || ncand > a.cand_cap || nres > a.rescan_cap;
+        const bool fb = force_fb || deep_overflow || ncand > a.cand_cap || nres > a.rescan_cap;
         a.counts[2 * q] = fb ? 0 : ncand;
         a.counts[2 * q + 1] = fb ? 0 : nres;
         a.fallback[q] = fb ? 1 : 0;
@@ -856,8 +869,8 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             const int pos = atomicAdd(a.fb_count, 1);
             a.fb_list[pos] = (int)q;
         } else {
-            atomicAdd(&a.stat_counters[0], (unsigned long long)ncand);
-            atomicAdd(&a.stat_counters[1], (unsigned long long)nres);
+            stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
+            stat_add(a.stat_counters, q, 1, (unsigned long long)nres);
         }
     }
 }

@@ -458,10 +458,10 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
                (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
     // (corpora of 8193..15360 rows whose chunking cannot give 4k superbins still have the dense path below)
 
-    ws.small.reserve(64);
-    VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
+    ws.small.reserve(kSmallBytes);
+    VDB_HIP(hipMemsetAsync(ws.small.p, 0, kSmallBytes, st));
     int32_t *fb_count = ws.small.as<int32_t>();
-    unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 16);
+    unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 64);
 
     const long tslot = timing_begin(h, st);
 
@@ -1104,18 +1104,20 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.last_candidates = s.last_rescan_bins = s.last_fallback_queries = 0;
         s.last_scan_ms = s.last_total_ms = 0.f;
         if (h->ws.small.p && (h->last.last_path == VDB_PATH_MFMA_SCAN || (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma))) {
-            unsigned char buf[64];
+            std::vector<unsigned char> buf(kSmallBytes);
             VDB_HIP(hipDeviceSynchronize());
-            VDB_HIP(hipMemcpy(buf, h->ws.small.p, 64, hipMemcpyDeviceToHost));
+            VDB_HIP(hipMemcpy(buf.data(), h->ws.small.p, kSmallBytes, hipMemcpyDeviceToHost));
             int32_t fb;
-            unsigned long long c[2];
-            memcpy(&fb, buf, 4);
-            memcpy(c, buf + 16, 16);
-            if (h->last.last_path == VDB_PATH_IVF) {
-                unsigned long long f2;
-                memcpy(&f2, buf + 32, 8);
-                fb = (int32_t)f2;
+            unsigned long long c[3] = {0, 0, 0};
+            memcpy(&fb, buf.data(), 4);
+            for (int sh = 0; sh < kStatShards; ++sh) {          // sharded counters (common.hpp, stat_add)
+                unsigned long long v[3];
+                memcpy(v, buf.data() + 64 + (size_t)sh * kStatStride * 8, 24);
+                c[0] += v[0];
+                c[1] += v[1];
+                c[2] += v[2];
             }
+            if (h->last.last_path == VDB_PATH_IVF) fb = (int32_t)c[2];
             s.last_fallback_queries = fb;
             s.last_candidates = (int64_t)c[0];
             s.last_rescan_bins = (int64_t)c[1];
