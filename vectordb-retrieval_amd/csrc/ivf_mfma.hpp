@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ivf_build_panels_kernel(const float *__re
         }
         panels[gid] = out;
     }
-    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
 __global__ __launch_bounds__(256) void ivf_build_bias_kernel(const float *__restrict__ xnorm2, int64_t nspans, int metric,

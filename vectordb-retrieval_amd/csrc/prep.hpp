@@ -6,8 +6,14 @@ namespace vdb {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// (every atomic below is guarded by a plain read of the current value: thousands of waves hitting ONE address with
+//  atomics that would not change it serialise in L2 -- the flags and maxima settle after the first few waves)
 __device__ __forceinline__ void atomic_max_bits(unsigned *addr, float v) {
-    atomicMax(addr, __float_as_uint(fabsf(v)));  // |v| >= 0: integer order == float order
+    const unsigned b = __float_as_uint(fabsf(v));  // |v| >= 0: integer order == float order
+    if (b > *reinterpret_cast<volatile unsigned *>(addr)) atomicMax(addr, b);
+}
+__device__ __forceinline__ void atomic_set_flag(int *addr) {
+    if (*reinterpret_cast<volatile int *>(addr) == 0) atomicOr(addr, 1);
 }
 
 // ---- corpus statistics + exact row norms -----------------------------------------------------------
@@ -44,8 +50,8 @@ __global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restri
     if ((threadIdx.x & 63) == 0) {
         atomic_max_bits(&st->absmax_bits, amax);
         atomic_max_bits(&st->maxnorm2_bits, n2);
-        if (anyf) atomicOr(&st->nonfinite, 1);
-        if (anyi) atomicOr(&st->not_integer, 1);
+        if (anyf) atomic_set_flag(&st->nonfinite);
+        if (anyi) atomic_set_flag(&st->not_integer);
     }
 }
 
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void build_panels_kernel(const float *__restri
         }
         panels[gid] = out;
     }
-    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
 // ---- 16-row-tile panels for v_mfma_f32_16x16x32_f16 (layout "p16", see common.hpp) ------------------------
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void build_panels16_kernel(const float *__rest
         }
         panels[gid] = out;
     }
-    if (__any(inexact) && (threadIdx.x & 63) == 0) atomicOr(&st->not_fp16_exact, 1);
+    if (__any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
 // bias (C-init of the MFMA accumulators): ||x||^2 for L2, 0 for IP, pad marker beyond N.
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
         flags = s_flags[0] | s_flags[1] | s_flags[2] | s_flags[3];
         atomic_max_bits(&info->absmax_bits, amax);
-        if (flags & 1) atomicOr(&info->nonfinite, 1);
-        if (flags & 2) atomicOr(&info->not_integer, 1);
+        if (flags & 1) atomic_set_flag(&info->nonfinite);
+        if (flags & 2) atomic_set_flag(&info->not_integer);
     }
 }
 
