@@ -22,6 +22,7 @@ __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src_lane) {
 
 template <int KPL>
 struct WaveTopK {
+    static constexpr int kBatchMin = 12;   // accepted pairs per offer() from which the batch merge beats serial insertion
     uint64_t key[KPL];
     int64_t id[KPL];
     int n;             // entries held (wave-uniform)
@@ -89,9 +90,98 @@ struct WaveTopK {
         }
     }
 
+    // compare-exchange of this lane's pair with the pair of lane ^ j: keep the smaller one if keep_min
+    __device__ __forceinline__ static void cex_lane(uint64_t &k_, int64_t &i_, int j, bool keep_min) {
+        const uint64_t ok = __shfl_xor(k_, j);
+        const int64_t oi = __shfl_xor(i_, j);
+        const bool other_less = pair_less(ok, oi, k_, i_);
+        if (other_less == keep_min) {
+            k_ = ok;
+            i_ = oi;
+        }
+    }
+
+    // Batch form of offer() for MANY accepted pairs (large k: the one-at-a-time insertion costs ~40-70 instructions
+    // per pair and made the top-k, not the distances, the cost of k >= 100 searches).  The <= 64 offered pairs are
+    // sorted across the lanes (bitonic network, 21 compare-exchange steps), reversed, and merged into the sorted list
+    // with one half-cleaner step against the list's last register followed by a bitonic merge of the list itself.
+    // Unused slots carry the sentinel (~0, INT64_MAX) while this runs; `n` keeps track of the real entries.
+    __device__ __forceinline__ void merge_batch(uint64_t bk, int64_t bi, int cnt) {
+        const int lane = threadIdx.x & 63;
+        // 1. sort the batch ascending over the lanes
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+            const bool asc = (lane & k2) == 0;          // (k2 == 64: every lane ascending)
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) cex_lane(bk, bi, j, ((lane & j) == 0) == asc);
+        }
+        // 2. reverse it (descending): list ascending ++ batch descending is a bitonic sequence
+        bk = __shfl(bk, 63 - lane);
+        bi = __shfl(bi, 63 - lane);
+        // sentinels in the unused slots of the list
+#pragma unroll
+        for (int e = 0; e < KPL; ++e)
+            if (e * 64 + lane >= n) {
+                key[e] = ~0ull;
+                id[e] = INT64_MAX;
+            }
+        // 3. half-cleaner: the virtual second half is (sentinel registers ..., batch); only the last register meets real data
+        if (pair_less(bk, bi, key[KPL - 1], id[KPL - 1])) {
+            key[KPL - 1] = bk;
+            id[KPL - 1] = bi;
+        }
+        // 4. the list is now bitonic and holds the KPL*64 smallest pairs: bitonic merge, register strides then lane strides
+#pragma unroll
+        for (int re = KPL >> 1; re > 0; re >>= 1) {
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+                if ((e & re) == 0) {
+                    const int o = e + re;
+                    if (pair_less(key[o], id[o], key[e], id[e])) {
+                        const uint64_t tk_ = key[e];
+                        const int64_t ti_ = id[e];
+                        key[e] = key[o];
+                        id[e] = id[o];
+                        key[o] = tk_;
+                        id[o] = ti_;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) cex_lane(key[e], id[e], j, (lane & j) == 0);
+        }
+        // 5. bookkeeping: the list holds min(n + cnt, k) entries; slots past k are dropped
+        n = (n + cnt < k) ? n + cnt : k;
+#pragma unroll
+        for (int e = 0; e < KPL; ++e)
+            if (e * 64 + lane >= n) {
+                key[e] = ~0ull;
+                id[e] = -1;
+            }
+        if (n == k) {
+            const int ts = k - 1;
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+                if (e == (ts >> 6)) {
+                    thr_key = bcast_u64(key[e], ts & 63);
+                    thr_id = (int64_t)bcast_u64((uint64_t)id[e], ts & 63);
+                }
+            }
+        }
+    }
+
     // every lane offers one pair (valid = false -> nothing offered)
     __device__ __forceinline__ void offer(uint64_t nk, int64_t nid, bool valid) {
-        uint64_t mask = __ballot(valid && beats_threshold(nk, nid));
+        const bool want = valid && beats_threshold(nk, nid);
+        uint64_t mask = __ballot(want);
+        const int cnt = __popcll(mask);
+        if (cnt >= kBatchMin) {
+            merge_batch(want ? nk : ~0ull, want ? nid : INT64_MAX, cnt);
+            return;
+        }
         while (mask) {
             const int src = __ffsll((unsigned long long)mask) - 1;
             mask &= mask - 1;
