@@ -38,6 +38,7 @@ struct ScanArgs {
     int nchunks;
     int nqtiles;           // query tiles (64 * NWAVES queries each)
     int64_t Qpad;          // multiple of 512
+    int64_t nq_valid;      // flat mode: queries >= nq_valid are padding (0 = unknown: treat every column as real)
     // ---- IVF ("items") mode: one workgroup = (one inverted list) x (one group of 64*NWAVES query slots) ----
     const int32_t *item_list;    // [items] list id
     const int32_t *item_slot0;   // [items] first query slot of the group
@@ -292,6 +293,19 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     stage_issue(0, 0);
     stage_bias_store(0);
     __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+
+    // A wave whose 64 query columns are all padding (the last query tile of a batch that is not a multiple of 512)
+    // only keeps staging and the barriers going: its partner on the SIMD gets the matrix pipe to itself.
+    if (!ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid) {
+        for (int st = 0; st < nstages; ++st) {
+            if (st + 1 < nstages) {
+                stage_issue(st + 1, (st & 1) ^ 1);
+                stage_bias_store((st & 1) ^ 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
 
     half8 fr[KSTEPS];
     float16v cin, acc0, acc1;

@@ -676,6 +676,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     sa.chunk_rem = g.rem;
     sa.nchunks = g.nchunks;
     sa.Qpad = Qpad;
+    sa.nq_valid = nq;
     if (h->scan_variant == 6) {   // diagnostic build: per-wave cycle sums
         const size_t nblocks = 8 * (size_t)((g.nchunks + 7) / 8) * (size_t)(Qpad / 512);
         ws.dense.reserve(nblocks * 8 * 8 * sizeof(unsigned long long));
