@@ -448,3 +448,19 @@ def test_fp16_scan_error_bound_holds_on_the_kloop_layout(vdb, d, metric):
     assert np.all(err <= bound), (d, metric, float(err.max()), float(bound.min()))
     assert float(err.max()) > 0.0       # (the hook really returns fp16-scan values, not exact ones)
     idx.close()
+
+
+def test_search_statistics_are_summed_over_the_counter_shards(vdb):
+    """vdb_stats after an MFMA-scan search: candidate quads / re-scanned bins / fallbacks are counted per query in
+    sharded device counters (common.hpp stat_add) and summed on the host."""
+    X, Q = _make(60000, 128, 700, "sift", 77)
+    idx = vdb.FlatIndex(128, "l2", 0)
+    idx.add(X)
+    k = 10
+    idx.search(Q, k)
+    st = idx.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["last_nq"] == 700
+    # every query needs at least ceil(k / 4) candidate quads (4 rows each) and stays within its work-list capacity
+    assert 700 * 3 <= st["last_candidates"] <= 700 * (2 * k + 32 + 32)
+    assert 0 <= st["last_rescan_bins"] <= 700 * 16 and st["last_fallback_queries"] == 0
+    idx.close()
