@@ -481,7 +481,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
         VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
         const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 512)), dim3(256), 0, st>>>(dq, total, info);
+        query_stats_kernel<<<dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 4096)), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0,
                                                           h->maxnorm2);
         const int64_t threads = (Qp / 32) * h->ksteps * 64;
@@ -489,7 +489,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             dq, nq, Dm, D4, h->ksteps, Qp / 32, info, ws.qpanels.as<half8>());
         EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
                    h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
-        query_eps_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(ea);
+        query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
         const int64_t ntiles = h->Npad / kTileRows;
         timing_mark(h, tslot, 0, st);
         {
@@ -647,7 +647,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
     {
         const int64_t total = nq * Dm;
-        const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 512);
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 4096);
         query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2);
         const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
@@ -657,7 +657,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, h->ksteps, Qpad / 32, info, ws.qpanels.as<half8>());
         EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
                    h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
-        query_eps_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(ea);
+        query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
         VDB_HIP(hipGetLastError());
     }
 
