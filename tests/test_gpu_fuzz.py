@@ -42,8 +42,10 @@ def _cases():
         ((32768, 70000), (3, 128), (1, 200)),      # flat MFMA scan
         ((32768, 50000), (129, 300), (1, 120)),    # K-loop MFMA scan (p16 panels)
     ]
+    import os
+    per_target = int(os.environ.get("VDBHIP_FUZZ_CASES", "10"))     # (a one-off deep sweep: VDBHIP_FUZZ_CASES=100)
     for t, (nr, dr, qr) in enumerate(targets):
-        for i in range(10):
+        for i in range(per_target):
             n = int(rng.integers(nr[0], nr[1] + 1))
             d = int(rng.integers(dr[0], dr[1] + 1))
             nq = int(rng.integers(qr[0], qr[1] + 1))
@@ -73,9 +75,10 @@ def test_random_shapes_and_distributions_bit_exact(oracle, target, i, n, d, nq, 
 
 
 def _ivf_cases():
+    import os
     rng = np.random.default_rng(77)
     out = []
-    for i in range(12):
+    for i in range(int(os.environ.get("VDBHIP_FUZZ_IVF_CASES", "12"))):
         n = int(rng.integers(2000, 70000))
         d = int(rng.integers(2, 200))
         nlist = int(rng.integers(2, min(400, n // 20)))
