@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic build of the flat scan kernel (scan_variant 6): per-wave shader-cycle sums of the stage head,
 MFMA phases, select phases and barrier waits.  Shares only: the stamped build is slower than the real one."""
+import os; os.environ.setdefault('VDBHIP_LIBRARY', os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vectordb-retrieval_amd', 'vdbhip', 'libvdbhip_ablations.so'))  # `make -C vectordb-retrieval_amd ablations`
 import ctypes, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the K-loop scan (D > 128) in ONE process: (scan_variant, kloop_qgroup) combinations on a device-
 generated Gaussian corpus; every combination must return the ids of the first one."""
+import os; os.environ.setdefault('VDBHIP_LIBRARY', os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vectordb-retrieval_amd', 'vdbhip', 'libvdbhip_ablations.so'))  # `make -C vectordb-retrieval_amd ablations`
 import argparse, json, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of scan-kernel variants in ONE process (cdna guide rule 24): rounds x variants,
 median / min of the HIP-event scan time and of the whole device pipeline."""
+import os; os.environ.setdefault('VDBHIP_LIBRARY', os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'vectordb-retrieval_amd', 'vdbhip', 'libvdbhip_ablations.so'))  # `make -C vectordb-retrieval_amd ablations`
 import argparse, json, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -193,6 +193,22 @@ def main() -> None:
         "r1": float(metrics.recall_at_k(gt, pr, 1)), "r2": float(metrics.recall_at_k(gt, pr, 2)),
         "r4": float(metrics.recall_at_k(gt, pr, 4)), "r10": float(metrics.recall_at_k(gt, pr, 10))}
 
+    # published result points of the reference (committed result JSONs + the config of that run): the only pins the
+    # reference holds for its FAISS-backed IVF path
+    import yaml
+
+    run = REF / "benchmark_results" / "benchmark_20260305_070532" / "random"
+    cfg = yaml.safe_load((run / "random_config.yaml").read_text())
+    ivf = json.loads((run / "ivf_flat_results.json").read_text())
+    exact = json.loads((run / "exact_results.json").read_text())
+    ip = ivf["parameters"]["indexer"]["params"]
+    manifest["published_points"] = {"random_ivf_flat": {
+        "source": "benchmark_results/benchmark_20260305_070532/random/{ivf_flat,exact}_results.json + random_config.yaml",
+        "dataset_options": cfg["dataset_options"], "config_seed": cfg["seed"], "n_queries": cfg["n_queries"],
+        "topk": cfg["topk"], "index_type": ip["index_type"], "nprobe": ip["nprobe"],
+        "ivf_flat": {"recall@1": ivf["recall@1"], "recall@10": ivf["recall@10"]},
+        "exact": {"recall@1": exact["recall@1"], "recall@10": exact["recall@10"]}}}
+
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     print(json.dumps(manifest, indent=1, sort_keys=True))
 

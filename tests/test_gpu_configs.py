@@ -1,0 +1,189 @@
+"""BASELINE.json configs 4 and 5 at their stated parameters, and the reference's published IVF point.
+
+config 4   SIFT1M-shaped 1M x 128, IVF-Flat nlist = 1024, nprobe 8 / 32 / 128, 10 000 queries (configs/sift1m.yaml:19-22
+           is the reference's IVF1000 analogue; modular.py:437-441, 544 set nprobe and search).  Injected centroids, so
+           oracle/ivf_oracle.c applies: sampled bit-exact parity, properties on every row, force_path = 1 equality.
+config 5   the per-GPU half of "100M x 768 over 8 GPUs": a 12.5M x 768 inner-product shard generated on device
+           (bench.device_rows, the generator bench.py uses), K-loop scan, 10 000 queries: sampled bit-exact parity
+           against the CPU oracle over ALL rows, properties on every row, 3-shard merge invariance at that size.
+published  configs/benchmark_config.yaml:154-163 (random 20 000 x 64, seed 7, 256 of 512 queries, topk 20) with
+           IVF100,Flat nprobe 10: recall@10 = 0.410546875, recall@1 = 0.4453125
+           (benchmark_results/benchmark_20260305_070532/random/ivf_flat_results.json:41-43); exact recall = 1.0.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def vdb():
+    import vdbhip
+
+    return vdbhip
+
+
+def _properties(D, I, lo, hi, metric):
+    assert D.shape == I.shape and I.dtype == np.int64 and D.dtype == np.float32
+    assert I.min() >= lo and I.max() < hi
+    steps = np.diff(D, axis=1)
+    assert np.all(steps >= 0) if metric == "l2" else np.all(steps <= 0)
+    srt = np.sort(I, axis=1)
+    assert np.all(srt[:, 1:] != srt[:, :-1]), "duplicate neighbour ids in a row"
+    ties = steps == 0                              # equal distances must be ordered by id
+    assert np.all(np.diff(I, axis=1)[ties] > 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 4
+# ---------------------------------------------------------------------------------------------------------
+def test_config4_ivf1024_sift1m_nprobe_8_32_128(vdb, oracle):
+    from vdbhip import datasets
+
+    X, Q = datasets.sift_like(1_000_000, 10_000, 128, 1234)
+    nlist, k = 1024, 10
+    C = X[np.random.default_rng(4).choice(len(X), nlist, replace=False)].copy()
+    C += np.random.default_rng(5).uniform(-0.25, 0.25, C.shape).astype(np.float32)   # no centroid ties on duplicate rows
+    idx = vdb.IVFFlatIndex(128, nlist, "l2", 0)
+    idx.set_centroids(C)
+    idx.add(X)
+    lor = idx.assignment()
+    rows = np.random.default_rng(6).choice(len(X), 50_000, replace=False)
+    np.testing.assert_array_equal(lor[rows], oracle.ivf_assign(C, X[rows], "l2"))
+    sample = np.random.default_rng(7).choice(len(Q), 48, replace=False)
+    prev_d = None
+    for nprobe in (8, 32, 128):
+        idx.set_nprobe(nprobe)
+        D, I = idx.search(Q, k)
+        st = idx.stats()
+        assert st["last_path_name"] == "ivf" and st["nlist"] == nlist and st["nprobe"] == nprobe
+        _properties(D, I, 0, len(X), "l2")
+        Do, Io = oracle.ivf_search(X, C, lor, Q[sample], k, nprobe, "l2")
+        np.testing.assert_array_equal(I[sample], Io)
+        np.testing.assert_array_equal(D[sample], Do)
+        # the exact list scan and the list-major MFMA scan agree bit for bit
+        idx.set_option("force_path", 1)
+        D1, I1 = idx.search(Q[:512], k)
+        idx.set_option("force_path", 0)
+        np.testing.assert_array_equal(I1, I[:512])
+        np.testing.assert_array_equal(D1, D[:512])
+        # probing more lists can only improve every k-th distance
+        if prev_d is not None:
+            assert np.all(D[:, -1] <= prev_d[:, -1])
+        prev_d = D
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 5 (per-GPU shard)
+# ---------------------------------------------------------------------------------------------------------
+def test_config5_marco_shard_12p5m_x_768(vdb, oracle):
+    torch = pytest.importorskip("torch")
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    n = int(os.environ.get("VDBHIP_TEST_MARCO_ROWS", "12500000"))
+    d, nq, k, metric = 768, 10_000, 10, "ip"
+    dev = torch.device("cuda:0")
+    X_t = bench.device_rows(n, d, 0, dev)
+    Q = np.random.default_rng(1235).standard_normal((nq, d), dtype=np.float32)
+    q_t = torch.from_numpy(Q).to(dev)
+    full = vdb.FlatIndex(d, metric, 0)
+    full.add_device(X_t.data_ptr(), n, id_base=0)
+    D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    full.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr())
+    torch.cuda.synchronize()
+    st = full.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, st
+    D, I = D_t.cpu().numpy(), I_t.cpu().numpy()
+    _properties(D, I, 0, n, metric)
+    full.close()
+
+    # sampled oracle parity over ALL rows: the corpus comes back in 2.5M-row slices, the oracle scores each slice
+    # (float64 keys + global ids) and merges them with its own (key, id) merge
+    sample = np.random.default_rng(8).choice(nq, 16, replace=False)
+    pk, pi = [], []
+    step = 2_500_000
+    for lo in range(0, n, step):
+        xs = X_t[lo:lo + step].cpu().numpy()
+        _, ids, keys = oracle.knn(xs, Q[sample], k, metric, id_base=lo, return_keys=True)
+        pk.append(keys)
+        pi.append(ids)
+        del xs
+    Do, Io = oracle.merge_partials(np.stack(pk), np.stack(pi), metric)
+    np.testing.assert_array_equal(I[sample], Io)
+    np.testing.assert_array_equal(D[sample], Do)
+
+    # 3 unequal shards of the same rows, partial lists merged on the device == the unsharded result
+    nqs = 2048
+    bounds = [0, n // 3 + 1, (2 * n) // 3 + 77, n]
+    parts = len(bounds) - 1
+    keys = torch.empty((parts, nqs, k), dtype=torch.float64, device=dev)
+    ids = torch.empty((parts, nqs, k), dtype=torch.int64, device=dev)
+    for p in range(parts):
+        s = vdb.FlatIndex(d, metric, 0)
+        s.add_device(X_t[bounds[p]:bounds[p + 1]].data_ptr(), bounds[p + 1] - bounds[p], id_base=bounds[p])
+        s.search_partial_device(q_t.data_ptr(), nqs, k, keys[p].data_ptr(), ids[p].data_ptr())
+        torch.cuda.synchronize()
+        s.close()
+    Dm = torch.empty((nqs, k), dtype=torch.float32, device=dev)
+    Im = torch.empty((nqs, k), dtype=torch.int64, device=dev)
+    vdb.merge_partials_device(metric, 0, keys.data_ptr(), ids.data_ptr(), parts, nqs, k, Dm.data_ptr(), Im.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(Im.cpu().numpy(), I[:nqs])
+    np.testing.assert_array_equal(Dm.cpu().numpy(), D[:nqs])
+    del X_t
+    torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's published random / IVF100,Flat point
+# ---------------------------------------------------------------------------------------------------------
+def test_published_random_ivf100_recall_point(vdb, golden_dir):
+    from vdbhip import datasets, harness
+    from vdbhip.metrics import recall_at_k
+
+    pub = json.loads((golden_dir / "manifest.json").read_text())["published_points"]["random_ivf_flat"]
+    opt = pub["dataset_options"]
+    train, test = datasets.random_reference(opt["dimensions"], opt["train_size"], opt["test_size"], opt["seed"])
+    gt = harness.ground_truth(train, test, k=opt["ground_truth_k"], metric="l2")
+    # the reference's query sub-selection: np.random.seed(config.seed) at the top of run(), then ONE
+    # np.random.choice(n_available, n_queries, replace=False) (experiment_runner.py:79, 148)
+    state = np.random.get_state()
+    try:
+        np.random.seed(pub["config_seed"])
+        sel = np.random.choice(len(test), pub["n_queries"], replace=False)
+    finally:
+        np.random.set_state(state)
+    q, g = test[sel], gt[sel]
+    topk = pub["topk"]
+
+    exact = vdb.CompositeAlgorithm("exact", opt["dimensions"],
+                                   indexer={"type": "HipBruteForceIndexer", "metric": "l2"},
+                                   searcher={"type": "HipLinearSearcher", "metric": "l2"}, metric="l2")
+    exact.build_index(train)
+    _, ie = exact.batch_search(q, k=topk)
+    assert recall_at_k(g, ie, 10) == pub["exact"]["recall@10"] == 1.0
+    assert recall_at_k(g, ie, 1) == 1.0
+
+    ivf = vdb.CompositeAlgorithm("ivf_flat", opt["dimensions"],
+                                 indexer={"type": "HipIVFIndexer", "metric": "l2", "index_type": pub["index_type"],
+                                          "nprobe": pub["nprobe"]},
+                                 searcher={"type": "HipIVFSearcher", "metric": "l2", "nprobe": pub["nprobe"]},
+                                 metric="l2")
+    ivf.build_index(train)
+    _, ii = ivf.batch_search(q, k=topk)
+    r10, r1 = recall_at_k(g, ii, 10), recall_at_k(g, ii, 1)
+    # FAISS's k-means is not reproducible without FAISS; on i.i.d. Gaussian data any Lloyd clustering into 100 cells
+    # probed 10 deep lands in the same neighbourhood
+    assert abs(r10 - pub["ivf_flat"]["recall@10"]) <= 0.05, (r10, pub["ivf_flat"]["recall@10"])
+    assert abs(r1 - pub["ivf_flat"]["recall@1"]) <= 0.08, (r1, pub["ivf_flat"]["recall@1"])

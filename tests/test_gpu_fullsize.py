@@ -102,10 +102,11 @@ def test_sift1m_shard_invariance(vdb, sift):
 
 
 def test_gaussian1m_and_glove_shapes(vdb, oracle):
+    """configs[1] Gaussian variant and configs[2] (GloVe-50 shape, inner product) with the full 10 000-query batch."""
     from vdbhip import datasets
 
-    for (X, Q), metric in ((datasets.gaussian(1_000_000, 4096, 128, 1234), "l2"),
-                           (datasets.glove_like(1_200_000, 4096, 50, 50), "ip")):
+    for (X, Q), metric in ((datasets.gaussian(1_000_000, 10_000, 128, 1234), "l2"),
+                           (datasets.glove_like(1_200_000, 10_000, 50, 50), "ip")):
         idx = vdb.FlatIndex(X.shape[1], metric, 0)
         idx.add(X)
         D, I = idx.search(Q, 10)
@@ -117,3 +118,25 @@ def test_gaussian1m_and_glove_shapes(vdb, oracle):
         np.testing.assert_array_equal(I[sample], Io)
         np.testing.assert_array_equal(D[sample], Do)
         idx.close()
+
+
+def test_glove_shape_cosine_through_the_plugin(vdb, oracle):
+    """configs[2] cosine variant at full size through BruteForceIndexer + LinearSearcher semantics
+    (modular.py:315-325, 363-385: both sides normalised, negated scores ascending)."""
+    from oracle import ref_semantics as rs
+    from vdbhip import datasets
+
+    X, Q = datasets.glove_like(1_200_000, 10_000, 50, 50)
+    algo = vdb.CompositeAlgorithm("exact_cos", 50, indexer={"type": "HipBruteForceIndexer", "metric": "cosine"},
+                                  searcher={"type": "HipLinearSearcher", "metric": "cosine"}, metric="cosine")
+    algo.build_index(X)
+    d, i = algo.batch_search(Q, k=10)
+    assert d.dtype == np.float32 and i.dtype == np.int64 and d.shape == (10_000, 10)
+    assert np.all(np.diff(d, axis=1) >= 0) and np.all(d <= 0) and np.all(d >= -1.0001)
+    assert i.min() >= 0 and i.max() < len(X)
+    sample = np.random.default_rng(5).choice(len(Q), 48, replace=False)
+    Xn, Qn = rs.safe_normalize(X), rs.safe_normalize(Q[sample])
+    Do, Io = oracle.knn(Xn, Qn, 10, "ip")
+    do, io = rs.flat_to_linear(Do, Io, "cosine")
+    np.testing.assert_array_equal(i[sample], io)
+    np.testing.assert_allclose(d[sample], do, rtol=1e-4, atol=1e-6)     # north_star: distances within 1e-4 relative

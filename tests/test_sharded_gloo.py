@@ -146,8 +146,23 @@ def _worker(rank, world, port, out_dir):
             algo.build_index(X)
             d, i = algo.batch_search(Q, k=7)
             d1, i1 = algo.search(Q[0], k=7)
+            # per-rank loader: rows [lo, hi) of a memory-mapped .npy / of an .fvecs file, nothing else
+            from vdbhip import io
+
+            npy, fv = Path(out_dir) / f"corpus_{metric}.npy", Path(out_dir) / f"corpus_{metric}.fvecs"
+            if rank == 0:
+                np.save(npy, X)
+                io.write_fvecs(fv, X)
+            dist.barrier()
+            res = {}
+            for tag, path in (("npy", npy), ("fvecs", fv)):
+                a2 = HipShardedExactSearch("sh_file", 24, metric=metric, engine_factory=_OracleEngine)
+                a2.build_index_from_file(str(path))
+                res[f"d_{tag}"], res[f"i_{tag}"] = a2.batch_search(Q, k=7)
+                res[f"shard_{tag}"] = np.array(a2.shard)
+                res[f"rows_{tag}"] = np.array(len(a2.engine.x))
             np.savez(Path(out_dir) / f"r{rank}_{metric}.npz", d=d, i=i, d1=d1, i1=i1,
-                     shard=np.array(algo.shard))
+                     shard=np.array(algo.shard), **res)
     finally:
         dist.destroy_process_group()
 
@@ -169,4 +184,9 @@ def test_two_gloo_ranks_equal_unsharded(tmp_path, oracle):
             np.testing.assert_array_equal(g["d"], d_ref)
             np.testing.assert_array_equal(g["i1"], i_ref[0])
             shards.append(tuple(g["shard"]))
+            for tag in ("npy", "fvecs"):                      # the file loader gives the same shards and results
+                np.testing.assert_array_equal(g[f"i_{tag}"], i_ref)
+                np.testing.assert_array_equal(g[f"d_{tag}"], d_ref)
+                assert tuple(g[f"shard_{tag}"]) == tuple(g["shard"])
+                assert int(g[f"rows_{tag}"]) == g["shard"][1] - g["shard"][0]      # only its own rows were handed over
         assert shards == [(0, 501), (501, 1001)]

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
         if (lane == 0) {
             a.fallback[q] = 1;
             a.fb_list[atomicAdd(a.fb_count, 1)] = (int)q;
+            stat_add(a.stat_counters, q, 2, 1ull);
         }
         return;
     }

@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         if (fb) {
             const int pos = atomicAdd(a.fb_count, 1);
             a.fb_list[pos] = (int)q;
+            stat_add(a.stat_counters, q, 2, 1ull);
         } else {
             stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
             stat_add(a.stat_counters, q, 1, (unsigned long long)nres);
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
         if (fb) {
             const int pos = atomicAdd(a.fb_count, 1);
             a.fb_list[pos] = (int)q;
+            stat_add(a.stat_counters, q, 2, 1ull);
         } else {
             stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
             stat_add(a.stat_counters, q, 1, (unsigned long long)nres);

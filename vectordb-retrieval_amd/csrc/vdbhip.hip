@@ -46,6 +46,14 @@ struct DevBuf {
     T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// temporary of one API call: freed on every exit path (an Error thrown by a later hipMalloc included)
+struct ScopedDevBuf : DevBuf {
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf &) = delete;
+    ScopedDevBuf &operator=(const ScopedDevBuf &) = delete;
+    ~ScopedDevBuf() { release(); }
+};
+
 struct Workspace {
     DevBuf qpad, qpanels, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
@@ -113,7 +121,21 @@ namespace {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-void set_device(int dev) { VDB_HIP(hipSetDevice(dev)); }
+// Entry points run on the handle's GPU and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) VDB_HIP(hipSetDevice(dev));
+        else prev = -1;
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define set_device(dev) DeviceGuard device_guard__(dev)
 
 constexpr size_t kMaxTimedCalls = 1024;
 
@@ -166,6 +188,7 @@ void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
     VDB_HIP(hipGetLastError());
 }
 
+constexpr double kBinBudget = 6.0 * 1024.0 * 1024.0 * 1024.0;   // bytes of level-1 bin arrays per search pass
 constexpr int64_t kDenseMaxRows = 15360;   // dense small-corpus path: one query's scores fit the default 64 KiB of LDS
 
 // ---- index build ---------------------------------------------------------------------------------
@@ -312,7 +335,7 @@ int scan_geometry_direct(const vdb_index_s *h, int k, ScanGeom &g) {
 struct ScanVariant { int nwaves, st, wps; };
 constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {4, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {4, 4, 2}, {8, 4, 2},
                                          {8, 4, 2}, {8, 4, 2}, {8, 4, 2}};
-constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
+[[maybe_unused]] constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
 template <int KSTEPS>
 void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16) {
@@ -327,6 +350,7 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
     const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
     switch (variant) {
+#ifdef VDB_ABLATIONS   // A/B schedules and timing-only ablations (WRONG RESULTS for 4, 7..9): scripts/sweep_scan.py builds
         case 1: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
         case 4: scan_kernel<KSTEPS, 8, 4, 2, 5><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 5: scan_kernel<KSTEPS, 4, 4, 2, 0, 16, false, 3><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
@@ -336,6 +360,7 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
         case 7: scan_kernel<KSTEPS, 8, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 8: scan_kernel<KSTEPS, 8, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
         case 9: scan_kernel<KSTEPS, 8, 4, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
+#endif
         default: scan_kernel<KSTEPS, 8, 4, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
     }
 }
@@ -360,16 +385,19 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
         }
         if (h->tile16) {
             switch (h->scan_variant) {
+#ifdef VDB_ABLATIONS
                 case 2: scan16_kloop_kernel<0, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
                 case 7: scan16_kloop_kernel<2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
                 case 8: scan16_kloop_kernel<3, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
                 case 9: scan16_kloop_kernel<4, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
+#endif
                 default: scan16_kloop_kernel<0, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             }
             VDB_HIP(hipGetLastError());
             return;
         }
         switch (h->scan_variant) {
+#ifdef VDB_ABLATIONS
             case 1: scan_kloop_kernel<0, 8, 1, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             case 2: scan_kloop_kernel<0, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
             case 3: scan_kloop_kernel<0, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
@@ -377,21 +405,29 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
             case 9: scan_kloop_kernel<4, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
             case 7: scan_kloop_kernel<2, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
             case 8: scan_kloop_kernel<3, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
+#endif
             default: scan_kloop_kernel<0, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
         }
     } else if (h->tile16) {            // D <= 128 on p16 panels
         sa.nqtiles = (int)(Qpad / 512);
         const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
         const int v = h->scan_variant;
+        (void)v;
         if (h->ksteps == 4) {
+#ifdef VDB_ABLATIONS
             if (v == 7) scan16_kernel<2, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
             else if (v == 8) scan16_kernel<2, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else scan16_kernel<2, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else
+#endif
+            scan16_kernel<2, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
         } else {
+#ifdef VDB_ABLATIONS
             if (v == 7) scan16_kernel<4, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
             else if (v == 8) scan16_kernel<4, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
             else if (v == 1) scan16_kernel<4, 4><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
+            else
+#endif
+            scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
         }
     } else if (h->ksteps == 4)
         launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st, bt);
@@ -458,8 +494,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
                (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
     // (corpora of 8193..15360 rows whose chunking cannot give 4k superbins still have the dense path below)
 
-    ws.small.reserve(kSmallBytes);
-    VDB_HIP(hipMemsetAsync(ws.small.p, 0, kSmallBytes, st));
+    // fb_count restarts with every batch (it indexes this batch's fb_list); the statistics counters behind it were
+    // zeroed once for the whole call (search_device_impl) and accumulate over the batches
+    VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
     int32_t *fb_count = ws.small.as<int32_t>();
     unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 64);
 
@@ -817,12 +854,27 @@ void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, floa
         h->last.last_path = VDB_PATH_EXACT_SCAN;
         return;
     }
-    const int64_t kBatch = 16384;
-    for (int64_t b0 = 0; b0 < nq; b0 += kBatch) {
-        const int64_t nb = std::min<int64_t>(kBatch, nq - b0);
-        search_batch(h, dq + (size_t)b0 * h->dim, nb, k, D ? D + (size_t)b0 * k : nullptr,
-                     I ? I + (size_t)b0 * k : nullptr, pk ? pk + (size_t)b0 * k : nullptr,
-                     pi ? pi + (size_t)b0 * k : nullptr, st);
+    // queries per pass: the level-1 bin arrays cost 8 bytes per (256-row bin, query); keep them within kBinBudget so
+    // that a large batch on a large shard is served in several passes instead of failing with VDB_ERR_NOMEM
+    int64_t kBatch = 16384;
+    {
+        const int64_t nbins = std::max<int64_t>(1, h->Npad / kBinRows);
+        const int64_t fit = (int64_t)(kBinBudget / (8.0 * (double)nbins)) / 512 * 512;
+        kBatch = std::max<int64_t>(512, std::min<int64_t>(kBatch, fit));
+    }
+    h->ws.small.reserve(kSmallBytes);
+    VDB_HIP(hipMemsetAsync(h->ws.small.p, 0, kSmallBytes, st));
+    const size_t ev_mark = h->ev_used;
+    try {
+        for (int64_t b0 = 0; b0 < nq; b0 += kBatch) {
+            const int64_t nb = std::min<int64_t>(kBatch, nq - b0);
+            search_batch(h, dq + (size_t)b0 * h->dim, nb, k, D ? D + (size_t)b0 * k : nullptr,
+                         I ? I + (size_t)b0 * k : nullptr, pk ? pk + (size_t)b0 * k : nullptr,
+                         pi ? pi + (size_t)b0 * k : nullptr, st);
+        }
+    } catch (...) {
+        h->ev_used = ev_mark;      // events of a failed search were never all recorded: do not leave them to vdb_stats
+        throw;
     }
 }
 
@@ -894,7 +946,7 @@ int vdb_create(int dim, int metric, int device, vdb_handle *out) {
 int vdb_destroy(vdb_handle h) {
     return guarded([&] {
         if (!h) return;
-        (void)hipSetDevice(h->device);
+        set_device(h->device);
         (void)hipDeviceSynchronize();
         DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
@@ -1070,7 +1122,7 @@ int vdb_rerank(vdb_handle hh, const float *q_host, int64_t nq, const int64_t *ca
         if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
         set_device(h->device);
         Workspace &ws = h->ws;
-        DevBuf dc;
+        ScopedDevBuf dc;
         ws.stage_q.reserve((size_t)nq * h->dim * sizeof(float));
         ws.stage_d.reserve((size_t)nq * k * sizeof(float));
         ws.stage_i.reserve((size_t)nq * k * sizeof(int64_t));
@@ -1084,7 +1136,6 @@ int vdb_rerank(vdb_handle hh, const float *q_host, int64_t nq, const int64_t *ca
         VDB_HIP(hipMemcpyAsync(D, ws.stage_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
         VDB_HIP(hipMemcpyAsync(I, ws.stage_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         VDB_HIP(hipStreamSynchronize(st));
-        dc.release();
     });
 }
 
@@ -1118,7 +1169,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
                 c[1] += v[1];
                 c[2] += v[2];
             }
-            if (h->last.last_path == VDB_PATH_IVF) fb = (int32_t)c[2];
+            fb = (int32_t)c[2];        // (counter 2 accumulates over the batches of a call; fb_count restarts per batch)
             s.last_fallback_queries = fb;
             s.last_candidates = (int64_t)c[0];
             s.last_rescan_bins = (int64_t)c[1];
@@ -1173,7 +1224,13 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;
         } else if (k == "scan_variant") {
+#ifdef VDB_ABLATIONS
             if (value < 0 || value >= kNumScanVariants) throw Error(VDB_ERR_INVALID, "scan_variant out of range");
+#else
+            // the A/B schedules and the timing-only ablations (some return wrong neighbours) exist only in
+            // -DVDB_ABLATIONS builds (`make ablations`, scripts/sweep_*.py); the shipped library has the one schedule
+            if (value != 0) throw Error(VDB_ERR_UNSUPPORTED, "scan_variant needs a -DVDB_ABLATIONS build of libvdbhip");
+#endif
             h->scan_variant = (int)value;
         } else if (k == "spans_per_chunk") {  // tuning: rows per workgroup chunk = 512 * value (0 = default 16)
             if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "spans_per_chunk out of range");

@@ -81,17 +81,23 @@ def all_gather_partials(pack, world: int):
     if world == 1:
         return pack.unsqueeze(0)
     out = torch.empty((world,) + tuple(pack.shape), dtype=pack.dtype, device=pack.device)
-    if pack.is_cuda:
+    if pack.is_cuda and dist.get_backend() == "nccl":       # the product path: RCCL, device buffers, one collective
         dist.all_gather_into_tensor(out, pack.contiguous())
-    else:  # gloo
-        dist.all_gather(list(out.unbind(0)), pack.contiguous())
+    else:  # gloo (CPU tests, and the shared-GPU rehearsal of tests/test_gpu_multirank.py): staged through the host
+        host = pack.contiguous().cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out.copy_(torch.stack(parts))
     return out
 
 
 class HipShardedExactSearch(BaseAlgorithm):
     """ExactSearch semantics (exact_search.py:6-78) over a corpus row-sharded across the ranks of the
-    current torch.distributed job.  Every rank passes the FULL corpus / query arrays (as the reference's
-    single-process harness would) and gets the full result back."""
+    current torch.distributed job.  `build_index(vectors)` takes the FULL corpus array on every rank, as the
+    reference's single-process harness would pass it -- a float32 `np.memmap` costs no host RAM, every rank only
+    touches the pages of its own row block.  `build_index_from_file(path)` is the per-rank loader for corpora that
+    are never materialised whole (100M x 768 = 307 GB): the file is memory-mapped and only rows [lo, hi) are read.
+    Every rank passes the same queries and gets the full result back."""
 
     def __init__(self, name: str, dimension: int, metric: str = "l2", device: Optional[int] = None,
                  engine_factory: Optional[Callable[[int, str, int], Any]] = None, **kwargs: Any) -> None:
@@ -111,18 +117,46 @@ class HipShardedExactSearch(BaseAlgorithm):
         return 0, 1
 
     def build_index(self, vectors: np.ndarray, metadata: Metadata = None) -> None:
-        import os
-
         self.rank, self.world = self._dist()
         x = _ffi.as_f32_c(vectors)
         if x.ndim != 2 or x.shape[1] != self.dimension:
             raise ValueError(f"expected (n, {self.dimension}) vectors, got {x.shape}")
         self.ntotal = int(x.shape[0])
         lo, hi = shard_bounds(self.ntotal, self.world, self.rank)
+        self._build_shard(x[lo:hi], lo, hi)
+
+    def build_index_from_file(self, path: str, limit: Optional[int] = None, metadata: Metadata = None) -> None:
+        """Per-rank loader: `path` is a 2-D float32 `.npy` (memory-mapped, dataset.py:376-471's cache format) or a
+        TEXMEX `.fvecs` file; this rank reads rows [lo, hi) of it and nothing else."""
+        from . import io
+
+        self.rank, self.world = self._dist()
+        if str(path).endswith(".fvecs"):
+            raw = np.memmap(path, dtype=np.int32, mode="r")
+            dim = int(raw[0]) if raw.size else self.dimension
+            if dim != self.dimension or raw.size % (dim + 1) != 0:
+                raise ValueError(f"{path}: not a .fvecs file of dimension {self.dimension}")
+            rec = raw.reshape(-1, dim + 1)
+            n = rec.shape[0] if limit is None else min(int(limit), rec.shape[0])
+            lo, hi = shard_bounds(n, self.world, self.rank)
+            x = np.ascontiguousarray(rec[lo:hi, 1:]).view(np.float32)
+        else:
+            arr = io.open_npy_rows(path, limit)
+            if arr.shape[1] != self.dimension:
+                raise ValueError(f"expected (n, {self.dimension}) vectors, got {arr.shape}")
+            n = int(arr.shape[0])
+            lo, hi = shard_bounds(n, self.world, self.rank)
+            x = arr[lo:hi]                                   # still a memmap: pages are read during the upload
+        self.ntotal = n
+        self._build_shard(_ffi.as_f32_c(x), lo, hi)
+
+    def _build_shard(self, rows: np.ndarray, lo: int, hi: int) -> None:
+        import os
+
         device = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", self.rank))
         factory = self._engine_factory or HipShardEngine
         self.engine = factory(self.dimension, self.metric, device)
-        self.engine.add(x[lo:hi], lo)
+        self.engine.add(rows, lo)
         self.shard = (lo, hi)
         self.index_built = True
 
