@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VDB_ABI_VERSION 1
+#define VDB_ABI_VERSION 2
 
 typedef struct vdb_index_s *vdb_handle;
 
@@ -73,6 +73,9 @@ typedef struct vdb_stats_s {
     float last_total_ms;       /* same for the whole device pipeline */
     int32_t nlist;             /* IVF: number of inverted lists (0 = flat index) */
     int32_t nprobe;
+    int32_t scan_dtype;        /* arithmetic of the last MFMA scan: 0 = fp16 (f32 accumulate), 1 = int8 (i32 accumulate) */
+    int32_t has_i8_copy;       /* 1 if the index holds the int8 scan copy (byte-valued integer corpus, D <= 128) */
+    int64_t last_rows_scanned; /* IVF: (query, row) pairs scanned by the last search (rows of the probed lists) */
 } vdb_stats_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -151,7 +154,10 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * recording HIP-event times of every search, averaged by vdb_stats), "list_cap" (work-list capacity per query),
  * tuning knobs used by scripts/: "scan_variant", "select_variant", "spans_per_chunk", "kloop_qgroup", and
  * "panel_layout" (0 auto: 16-row-tile panels for D > 128; 1: 32-row tiles for every D; 2: 16-row tiles for every D;
- * takes effect at the next vdb_add). */
+ * takes effect at the next vdb_add), "panel_dtype" (0 auto: byte-valued integer corpora are ALSO kept as an int8 scan
+ * copy and integer query batches in the byte window are scanned with int8 MFMA; 1: fp16 scan only).
+ * "scan_variant" and the other A/B knobs exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped library
+ * rejects them. */
 int vdb_set_option(vdb_handle h, const char *key, double value);
 
 /* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */

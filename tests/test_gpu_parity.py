@@ -464,3 +464,79 @@ def test_search_statistics_are_summed_over_the_counter_shards(vdb):
     assert 700 * 3 <= st["last_candidates"] <= 700 * (2 * k + 32 + 32)
     assert 0 <= st["last_rescan_bins"] <= 700 * 16 and st["last_fallback_queries"] == 0
     idx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# int8 scan copy (scan_i8.hpp): byte-valued integer corpora, chosen per batch on the device
+# ------------------------------------------------------------------------------------------------
+def _bytes_data(n, d, nq, window, seed, extreme=False):
+    rng = np.random.default_rng(seed)
+    lo, hi = (0, 255) if window == "u8" else (-128, 127)
+    if extreme:      # rows / queries pinned to the ends of the window: largest |dot|, |bias| the accumulators can meet
+        X = rng.choice(np.array([lo, hi], np.float32), size=(n, d))
+        Q = rng.choice(np.array([lo, hi], np.float32), size=(nq, d))
+        X[: n // 3] = rng.integers(lo, hi + 1, size=(n // 3, d)).astype(np.float32)
+    else:
+        X = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(n, d))), 0, 255).astype(np.float32) + (0 if window == "u8" else -128)
+        Q = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(nq, d))), 0, 255).astype(np.float32) + (0 if window == "u8" else -128)
+    return X, Q
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric,window,extreme", [
+    (65536, 128, 256, 10, "l2", "u8", False),
+    (70001, 128, 1000, 10, "ip", "u8", False),
+    (40000, 64, 130, 10, "l2", "u8", False),       # two 32-dim k-steps
+    (50000, 50, 77, 7, "l2", "s8", False),         # padded dims, s8 window
+    (50000, 100, 600, 20, "ip", "s8", False),
+    (120000, 96, 200, 100, "l2", "u8", False),     # k = 100 through the bins
+    (40000, 128, 300, 10, "l2", "u8", True),       # extremes of the window: overflow margins of t' and of the packing
+    (40000, 128, 300, 10, "ip", "s8", True),
+    (40000, 128, 300, 10, "l2", "s8", True),
+])
+def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metric, window, extreme):
+    X, Q = _bytes_data(n, d, nq, window, seed=n + d, extreme=extreme)
+    idx = vdb.FlatIndex(d, metric, 0)
+    idx.add(X, id_base=3)
+    D, I = idx.search(Q, k)
+    st = idx.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["has_i8_copy"] == 1 and st["scan_dtype"] == 1, st
+    assert st["last_fallback_queries"] == 0 or extreme, st
+    Do, Io = oracle.knn(X, Q, k, metric, id_base=3)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    # the fp16 scan of the same index (option panel_dtype = 1) agrees bit for bit
+    idx.set_option("panel_dtype", 1)
+    D1, I1 = idx.search(Q, k)
+    assert idx.stats()["scan_dtype"] == 0
+    np.testing.assert_array_equal(I1, I)
+    np.testing.assert_array_equal(D1, D)
+    idx.set_option("panel_dtype", 0)
+    # a batch with one non-integer value, or one value outside the byte window, is served by the fp16 scan
+    for bad in (0.5, 300.0):
+        Q2 = Q.copy()
+        Q2[nq // 2, d // 2] = bad
+        D2, I2 = idx.search(Q2, k)
+        assert idx.stats()["scan_dtype"] == 0
+        Do2, Io2 = oracle.knn(X, Q2, k, metric, id_base=3)
+        np.testing.assert_array_equal(I2, Io2)
+        np.testing.assert_array_equal(D2, Do2)
+    # queries in the OTHER byte window still use the int8 scan (the windows of corpus and queries are independent)
+    other = Q - 128 if window == "u8" else Q + 128
+    D3, I3 = idx.search(other, k)
+    assert idx.stats()["scan_dtype"] == 1
+    Do3, Io3 = oracle.knn(X, other, k, metric, id_base=3)
+    np.testing.assert_array_equal(I3, Io3)
+    np.testing.assert_array_equal(D3, Do3)
+    idx.close()
+
+
+def test_int8_copy_only_for_byte_valued_corpora(vdb):
+    rng = np.random.default_rng(0)
+    for X, want in ((rng.standard_normal((40000, 64)).astype(np.float32), 0),
+                    (rng.integers(0, 300, size=(40000, 64)).astype(np.float32), 0),        # integers beyond one byte
+                    (rng.integers(-128, 128, size=(40000, 64)).astype(np.float32), 1),
+                    (rng.integers(0, 256, size=(40000, 200)).astype(np.float32), 0)):      # D > 128: K-loop path
+        idx = vdb.FlatIndex(X.shape[1], "l2", 0)
+        idx.add(X)
+        assert idx.stats()["has_i8_copy"] == want
+        idx.close()

@@ -48,7 +48,9 @@ struct IndexStats {       // filled on device by the corpus-prep kernels
     int nonfinite;        // any NaN/Inf
     int not_integer;      // any non-integer value
     int not_fp16_exact;   // any value changed by the scaled fp16 conversion
-    int pad[3];
+    int not_u8;           // any value outside the integers 0..255      (int8 scan copy, window "u8": stored as x - 128)
+    int not_s8;           // any value outside the integers -128..127   (window "s8": stored as is)
+    int pad[1];
 };
 
 struct QueryBatchInfo {   // per search call, device resident
@@ -60,7 +62,24 @@ struct QueryBatchInfo {   // per search call, device resident
     float cs;             // sq * sx : scale of the scan scores
     float bscale;         // factor applied to the B operand (-2*sq for L2, -sq for IP)
     int force_fallback;   // scales unusable (non-finite input / overflow): every query takes the exhaustive path
+    int not_u8, not_s8;   // query values outside the integers 0..255 / -128..127
+    int i8_mode;          // 0: fp16 scan.  1 / 2: int8 scan (scan_i8.hpp), queries in the u8 / s8 window
 };
+
+// ---- int8 scan copy (scan_i8.hpp) ---------------------------------------------------------------------------------
+// Integer corpora whose values fit one byte (SIFT descriptors are uint8) get a second scan copy for
+// v_mfma_i32_32x32x32_i8 (twice the fp16 MFMA rate per clock, exact int32 accumulation).  Operands: A = x - cx,
+// B = cq - q with (cx, cq) = (128, 127) in the u8 window and (0, -1) in the s8 window, so both fit [-128, 127].
+//   sum_d A*B = -(x.q) + cq*sum(x) + cx*sum(q) - D*cx*cq
+// L2 order key ||x||^2 - 2 x.q = 2*dot + (||x||^2 - 2*cq*sum(x)) + const(q); the accumulator starts from
+// floor(bias/2) + kI8Offset and holds t' = dot + floor(bias/2) + kI8Offset, i.e. half the key up to the dropped
+// parity bit (|error| <= 1/2 in t units: the select widens its threshold by one).  IP: -x.q = dot - cq*sum(x) + const.
+// The offset makes every t' positive, the select packs v = (t' << 6) | quad id, and v read as a float bit pattern
+// is a normal positive float whose order is the integer order -- the bin arrays and the select kernels are shared
+// with the fp16 path (only T^ = tau + 2 eps is formed in integer arithmetic).
+constexpr int kI8Offset = 1 << 24;
+constexpr int kI8PadBias = 30000000;          // accumulator init of padding rows: above every real t', (t' << 6) < +inf bits
+constexpr unsigned kI8Inf = 0x7f800000u;      // "+inf" of the packed integer keys (bits of float +inf)
 
 // work list entry of the refine kernel: rows [row0, row0+count)
 struct Range {

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restri
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float amax = 0.f;
     float n2 = 0.f;
-    int nonfinite = 0, notint = 0;
+    int nonfinite = 0, notint = 0, notu8 = 0, nots8 = 0;
     if (row < N) {
         const float4 *xv = reinterpret_cast<const float4 *>(X + (size_t)row * D4);
         double acc = 0.0;
@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restri
                 amax = fmaxf(amax, fabsf(v[j]));
                 nonfinite |= !(fabsf(v[j]) <= 3.402823466e+38f);
                 notint |= (v[j] != rintf(v[j]));
+                notu8 |= !(v[j] >= 0.f && v[j] <= 255.f);
+                nots8 |= !(v[j] >= -128.f && v[j] <= 127.f);
             }
         }
         n2 = (float)acc;
@@ -46,12 +48,14 @@ __global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restri
         amax = fmaxf(amax, __shfl_xor(amax, o));
         n2 = fmaxf(n2, __shfl_xor(n2, o));
     }
-    const int anyf = __any(nonfinite), anyi = __any(notint);
+    const int anyf = __any(nonfinite), anyi = __any(notint), anyu = __any(notu8 | notint), anys = __any(nots8 | notint);
     if ((threadIdx.x & 63) == 0) {
         atomic_max_bits(&st->absmax_bits, amax);
         atomic_max_bits(&st->maxnorm2_bits, n2);
         if (anyf) atomic_set_flag(&st->nonfinite);
         if (anyi) atomic_set_flag(&st->not_integer);
+        if (anyu) atomic_set_flag(&st->not_u8);
+        if (anys) atomic_set_flag(&st->not_s8);
     }
 }
 
@@ -137,11 +141,12 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
     __shared__ float s_max[4];
     __shared__ int s_flags[4];
     float amax = 0.f;
-    int flags = 0;  // bit0 non-finite, bit1 non-integer
+    int flags = 0;  // bit0 non-finite, bit1 non-integer, bit2 outside 0..255, bit3 outside -128..127
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = Q[i];
         amax = fmaxf(amax, fabsf(v));
-        flags |= (!(fabsf(v) <= 3.402823466e+38f)) | ((v != rintf(v)) << 1);
+        flags |= (!(fabsf(v) <= 3.402823466e+38f)) | ((v != rintf(v)) << 1) | ((!(v >= 0.f && v <= 255.f)) << 2) |
+                 ((!(v >= -128.f && v <= 127.f)) << 3);
     }
     for (int o = 32; o > 0; o >>= 1) {
         amax = fmaxf(amax, __shfl_xor(amax, o));
@@ -158,12 +163,15 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         atomic_max_bits(&info->absmax_bits, amax);
         if (flags & 1) atomic_set_flag(&info->nonfinite);
         if (flags & 2) atomic_set_flag(&info->not_integer);
+        if (flags & 6) atomic_set_flag(&info->not_u8);
+        if (flags & 10) atomic_set_flag(&info->not_s8);
     }
 }
 
 // one thread: choose the power-of-two query scale for this batch
+// corpus_i8: the index holds an int8 scan copy and this search may use it (0 = fp16 scan only)
 __global__ void query_finalize_kernel(QueryBatchInfo *info, float sx, int metric, int corpus_int_unscaled,
-                                      float maxnorm2) {
+                                      float maxnorm2, int corpus_i8 = 0) {
     const float amax = __uint_as_float(info->absmax_bits);
     const float f = (metric == 0) ? 2.f : 1.f;
     float sq = 1.f;
@@ -178,6 +186,8 @@ __global__ void query_finalize_kernel(QueryBatchInfo *info, float sx, int metric
     info->bscale = -f * sq;
     const float top = sq * sx * maxnorm2;
     info->force_fallback = (info->nonfinite || !(top < 1.0e30f) || !(sq * sx > 1.0e-30f)) ? 1 : 0;
+    info->i8_mode = 0;
+    if (corpus_i8 && !info->nonfinite) info->i8_mode = !info->not_u8 ? 1 : (!info->not_s8 ? 2 : 0);
 }
 
 // fp16 B-fragment panels of the query batch + padded float32 copy for the refine kernel.
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restr
     const int64_t tk = gid >> 6;
     const int ks = (int)(tk % ksteps);
     const int64_t qt = tk / ksteps;
-    if (qt >= nqtiles) return;
+    if (qt >= nqtiles || info->i8_mode) return;
     const float bs = info->bscale;
     const int64_t q = qt * 32 + (lane & 31);
     const int d0 = ks * 16 + (lane >> 5) * 8;
@@ -262,6 +272,11 @@ __global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
     const int64_t q = gid >> 4;
     const int part = (int)(gid & 15);
     const bool qv = q < a.nq;
+    if (a.info->i8_mode) {     // int8 scan: exact integers; L2 drops the parity bit of the bias (1/2 in t units, so
+        // 2*eps = 1).  The select adds the BITS of eps[q] to the packed key: (2 eps) << 6.
+        if (qv && part == 0) a.eps[q] = __int_as_float(a.metric == 0 ? 64 : 0);
+        return;
+    }
     const float bs = a.info->bscale;
     const double cs = (double)a.info->cs;
     double n2 = 0.0;

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
     auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
+    if (!ITEMS && a.info->i8_mode) return;                  // this batch is served by scan_i8_kernel (scan_i8.hpp)
 
     // ---- block -> (chunk, query tile), XCD aware; or -> IVF work item -----------------------------
     const int tid = threadIdx.x, lane = tid & 63;
@@ -635,6 +636,13 @@ struct SelectArgs {
     unsigned long long *stat_counters;  // [2] total candidates, total rescans
 };
 
+// T^ = tau + 2 eps.  fp16 scan: float scores.  int8 scan (scan_i8.hpp): the values are packed integer keys
+// (t' << 6 | quad id) stored as float bit patterns and eps[q] carries the BITS of (2 eps) << 6: every key whose t' is
+// within the bound compares <= ((tau's t' << 6) | 63) + that increment; integer add on the bit patterns.
+__device__ __forceinline__ float select_threshold(float tau, float eps, int i8_mode) {
+    return i8_mode ? __int_as_float((__float_as_int(tau) | 63) + __float_as_int(eps)) : tau + 2.0f * eps;
+}
+
 template <int VPL>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const int lane = threadIdx.x & 63;
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         if (cnt < a.k) ans |= (1u << bit);
     }
     const float tau = unsortable_f32(ans);
-    const float that = tau + 2.0f * a.eps[q];
+    const float that = select_threshold(tau, a.eps[q], a.info->i8_mode);
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
 
     int ncand = 0, nres = 0;  // wave-uniform
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
         if (cnt < a.k) ans |= (1u << bit);
     }
     const float tau = unsortable_f32(ans);
-    const float that = tau + 2.0f * (qvalid ? a.eps[q] : 0.f);
+    const float that = select_threshold(tau, qvalid ? a.eps[q] : 0.f, a.info->i8_mode);
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
     __syncthreads();  // counters zeroed
     int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1], *cnt_d = &s_cnt[wave][qi][2];

@@ -1,0 +1,330 @@
+// scan_i8.hpp -- int8 MFMA form of the flat scan for byte-valued integer corpora (SIFT descriptors are uint8).
+//
+// Same work decomposition, LDS staging, row mapping, bins, superbins and outputs as scan_kernel (scan.hpp); what
+// changes is the arithmetic: v_mfma_i32_32x32x32_i8 (32 dims per k-step, twice the fp16 MFMA rate per clock, exact
+// int32 accumulation) on A = x - cx, B = cq - q (common.hpp, "int8 scan copy"), accumulator initialised with the
+// per-row integer bias, and an integer select: per quad  min3 + min, v_lshl_or (t' << 6 | quad id), med3 + min.
+// The packed keys are stored as float bit patterns (normal positive floats ordered like the integers), so the select
+// kernels of scan.hpp read them unchanged.  Which of the two scans serves a batch is decided ON THE DEVICE
+// (QueryBatchInfo.i8_mode, set by query_finalize_kernel from the query statistics): both kernels are enqueued and the
+// one that is not needed returns at once -- vdb_search_device stays asynchronous.
+#pragma once
+#include "common.hpp"
+#include "prep.hpp"
+#include "scan.hpp"
+
+namespace vdb {
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int16v __attribute__((ext_vector_type(16)));
+
+// ---- build: int8 panels in A-fragment order --------------------------------------------------------------------------
+// panels8[tile][ks][lane][16 x int8]: lane l holds MFMA row (l & 31) -- same row mapping as the fp16 panels -- dims
+// 32*ks + 16*(l >> 5) .. +15, value x - cx (0 beyond D or N).  One thread per (tile, ks, lane).
+__global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
+                                                              int ks32, int64_t ntiles, int cx,
+                                                              int4v *__restrict__ panels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ks32);
+    const int64_t tile = tk / ks32;
+    if (tile >= ntiles) return;
+    const int rho = lane & 31, kh = lane >> 5;
+    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+    const int64_t span = tile / kTilesPerSpan;
+    const int t = (int)(tile - span * kTilesPerSpan);
+    const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+    const int d0 = ks * 32 + kh * 16;
+    int4v out;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int d = d0 + 4 * w + b;
+            int v = 0;
+            if (row < N && d < D) v = (int)X[(size_t)row * D4 + d] - cx;
+            word |= ((unsigned)v & 0xffu) << (8 * b);
+        }
+        out[w] = (int)word;
+    }
+    panels[gid] = out;
+}
+
+// accumulator init per row, for both query windows: bias8[w][row], w = 0 (cq = 127), 1 (cq = -1)
+//   L2: floor((||x||^2 - 2 cq sum(x)) / 2) + kI8Offset     IP: -cq sum(x) + kI8Offset     padding rows: kI8PadBias
+__global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restrict__ X, int64_t N, int64_t Npad, int D,
+                                                            int D4, int metric, int32_t *__restrict__ bias8) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Npad) return;
+    if (row >= N) {
+        bias8[row] = kI8PadBias;
+        bias8[Npad + row] = kI8PadBias;
+        return;
+    }
+    long long n2 = 0, s1 = 0;
+    for (int d = 0; d < D; ++d) {
+        const long long v = (long long)X[(size_t)row * D4 + d];
+        n2 += v * v;
+        s1 += v;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const long long cq = w == 0 ? 127 : -1;
+        const long long b = metric == 0 ? ((n2 - 2 * cq * s1) >> 1) : -cq * s1;    // (>> on a negative: floor)
+        bias8[(size_t)w * Npad + row] = (int32_t)(b + kI8Offset);
+    }
+}
+
+// B fragments: qpanels8[qtile32][ks][lane][16 x int8], lane l holds query column l & 31, dims 32*ks + 16*(l>>5) .. +15,
+// value cq - q.  One thread per (qtile32, ks, lane).
+__global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int ks32,
+                                                               int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
+                                                               int4v *__restrict__ qpanels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ks32);
+    const int64_t qt = tk / ks32;
+    const int mode = info->i8_mode;
+    if (qt >= nqtiles || !mode) return;
+    const int cq = mode == 1 ? 127 : -1;
+    const int64_t q = qt * 32 + (lane & 31);
+    const int d0 = ks * 32 + (lane >> 5) * 16;
+    int4v out;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int d = d0 + 4 * w + b;
+            int v = 0;
+            if (q < nq && d < D) v = cq - (int)Q[(size_t)q * D + d];
+            word |= ((unsigned)v & 0xffu) << (8 * b);
+        }
+        out[w] = (int)word;
+    }
+    qpanels[gid] = out;
+}
+
+// ---- the scan ------------------------------------------------------------------------------------------------------
+struct ScanI8Args {
+    const int4v *panels;     // [ntiles][KS][64]
+    const int32_t *bias8;    // [2][Npad]
+    const int4v *qpanels;    // [Qpad/32][KS][64]
+    const QueryBatchInfo *info;
+    float *bin_m1, *bin_m2;  // [nspans*2][Qpad]   packed keys as float bit patterns
+    float *sb_m1, *sb_m2;    // [nchunks*2][Qpad]
+    int32_t *sb_span;
+    int64_t nspans, Npad, Qpad, nq_valid;
+    int spans_per_chunk, chunk_rem, nchunks, nqtiles;
+};
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }   // v_med3_i32
+
+// select of one tile: per column block 4 quads of 4 consecutive corpus rows; v = (min of the quad << 6) | quad id
+__device__ __forceinline__ void select_phase_i8(const int16v &acc0, const int16v &acc1, int (&m1)[2], int (&m2)[2],
+                                                unsigned id0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int q0 = imin(imin(acc0[4 * g], acc0[4 * g + 1]), imin(acc0[4 * g + 2], acc0[4 * g + 3]));
+        const int v0 = (int)(((unsigned)q0 << 6) | (id0 + g));
+        m2[0] = imed3(m1[0], m2[0], v0);
+        m1[0] = imin(m1[0], v0);
+        const int q1 = imin(imin(acc1[4 * g], acc1[4 * g + 1]), imin(acc1[4 * g + 2], acc1[4 * g + 3]));
+        const int v1 = (int)(((unsigned)q1 << 6) | (id0 + g));
+        m2[1] = imed3(m1[1], m2[1], v1);
+        m1[1] = imin(m1[1], v1);
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void read_phase_i8(const int4v *__restrict__ A_tile, const int4v *__restrict__ c_tile,
+                                              int4v (&fr)[KS], int16v &cin, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fr[ks] = A_tile[ks * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int4v c = c_tile[g];
+        cin[4 * g + 0] = c.x; cin[4 * g + 1] = c.y; cin[4 * g + 2] = c.z; cin[4 * g + 3] = c.w;
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v (&b0)[KS], const int4v (&b1)[KS],
+                                              const int16v &cin, int16v &acc0, int16v &acc1) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[ks], b0[ks], ks == 0 ? cin : acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[ks], b1[ks], ks == 0 ? cin : acc1, 0, 0, 0);
+    }
+}
+
+// KS: 32-dim k-steps (D padded to 32*KS: 2 or 4); ST: tiles per LDS stage.  8 waves, 2 per SIMD, phase-staggered halves
+// exactly as scan_kernel: the early half runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).
+template <int KS, int ST>
+__global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
+    constexpr int NWAVES = 8, NT = 512, BT = 16;
+    constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
+    constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
+    constexpr int SPS = kTilesPerSpan / ST;
+    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && BT % ST == 0, "bad geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
+    const int mode = a.info->i8_mode;
+    if (!mode) return;                                    // this batch is served by the fp16 scan
+    auto lds_a = [&](int buf) { return reinterpret_cast<int4v *>(smem + buf * (kStageVec * 16)); };
+    auto lds_b = [&](int buf) { return reinterpret_cast<int *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const bool late = wave >= NWAVES / 2;
+    const int b = blockIdx.x;
+    const int x = b & 7, j = b >> 3;
+    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+    const int chunk = x + 8 * ci;
+    if (chunk >= a.nchunks) return;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;
+    const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+    int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
+    if (span1 > a.nspans) span1 = a.nspans;
+    const int64_t out_col = q0 + (lane & 31);
+    const int32_t *bias = a.bias8 + (mode == 1 ? 0 : a.Npad);
+
+    int4v b0[KS], b1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        b0[ks] = a.qpanels[((size_t)(q0 / 32 + 0) * KS + ks) * 64 + lane];
+        b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KS + ks) * 64 + lane];
+    }
+    const int nstages = (int)(span1 - span0) * SPS;
+    const int INF = (int)kI8Inf;
+    int m1[2] = {INF, INF}, m2[2] = {INF, INF};
+    int M1[2] = {INF, INF}, M2[2] = {INF, INF};
+    int Ms[2] = {0, 0};
+
+    constexpr int kPieces = kStageVec / 64;
+    static_assert(kPieces % NWAVES == 0, "pieces must divide over the waves");
+    int stage_b[kBiasLoads];
+    auto stage_issue = [&](int st, int buf) {
+        const int64_t span = span0 + st / SPS;
+        const int sq = st % SPS;
+        const int4v *src = a.panels + ((size_t)(span * kTilesPerSpan + sq * ST) * KS) * 64;
+        int4v *dst = lds_a(buf);
+#pragma unroll
+        for (int i = 0; i < kPieces / NWAVES; ++i) {
+            const int p = wave + i * NWAVES;
+            const int4v *g = src + p * 64 + lane;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
+                reinterpret_cast<__attribute__((address_space(3))) void *>(
+                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < kBiasLoads; ++i) {
+            const int e = tid + i * NT;
+            if (e < ST * 32) {
+                const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+                stage_b[i] = bias[span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r];
+            }
+        }
+    };
+    auto stage_bias_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kBiasLoads; ++i)
+            if (tid + i * NT < ST * 32) lds_b(buf)[tid + i * NT] = stage_b[i];
+    };
+    auto flush_bin = [&](int64_t span) {
+        const size_t o = (size_t)(span * 2 + h) * a.Qpad + out_col;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            a.bin_m1[o + cb * 32] = __int_as_float(m1[cb]);
+            a.bin_m2[o + cb * 32] = __int_as_float(m2[cb]);
+            M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
+            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+            M1[cb] = imin(M1[cb], m1[cb]);
+            m1[cb] = INF;
+            m2[cb] = INF;
+        }
+    };
+
+    stage_issue(0, 0);
+    stage_bias_store(0);
+    __syncthreads();
+
+    if (a.nq_valid > 0 && q0 >= a.nq_valid) {            // all 64 query columns are padding: keep staging + barriers going
+        for (int st = 0; st < nstages; ++st) {
+            if (st + 1 < nstages) {
+                stage_issue(st + 1, (st & 1) ^ 1);
+                stage_bias_store((st & 1) ^ 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    int4v fr[KS];
+    int16v cin, acc0, acc1;
+    if (!late) {
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const int4v *A = lds_a(buf);
+            const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
+            const int ts0 = (st % SPS) * ST;
+            read_phase_i8<KS>(A, B4, fr, cin, lane);
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase_i8<KS>(fr, b0, b1, cin, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
+                select_phase_i8(acc0, acc1, m1, m2, (unsigned)(((ts0 + t) % BT) << 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = (int)(kI8Inf >> 6);   // dummy "previous tile": (x << 6) == "+inf", never wins
+        acc1 = acc0;
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const int4v *A = lds_a(buf);
+            const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
+            const int ts0 = (st % SPS) * ST;
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_phase_i8<KS>(A + t * KS * 64, B4 + t * 8, fr, cin, lane);
+                const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
+                select_phase_i8(acc0, acc1, m1, m2, (unsigned)((tp % BT) << 2));
+                if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase_i8<KS>(fr, b0, b1, cin, acc0, acc1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            __syncthreads();
+        }
+        select_phase_i8(acc0, acc1, m1, m2, (unsigned)((BT - 1) << 2));
+        flush_bin(span1 - 1);
+    }
+
+    const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        a.sb_m1[so + cb * 32] = __int_as_float(M1[cb]);
+        a.sb_m2[so + cb * 32] = __int_as_float(M2[cb]);
+        a.sb_span[so + cb * 32] = Ms[cb];
+    }
+}
+
+}  // namespace vdb

@@ -13,6 +13,7 @@
 #include "refine.hpp"
 #include "scan.hpp"
 #include "scan16.hpp"
+#include "scan_i8.hpp"
 #include "ivf.hpp"
 #include "ivf_mfma.hpp"
 #include "dense.hpp"
@@ -55,13 +56,13 @@ struct ScopedDevBuf : DevBuf {
 };
 
 struct Workspace {
-    DevBuf qpad, qpanels, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
+    DevBuf qpad, qpanels, qpanels8, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
-        const DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
                                &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
                                &stage_i, &dense};
         size_t s = 0;
@@ -69,7 +70,7 @@ struct Workspace {
         return s;
     }
     void release() {
-        DevBuf *all[] = {&qpad, &qpanels, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
                          &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
                          &dense};
         for (auto b : all) b->release();
@@ -85,6 +86,11 @@ struct vdb_index_s {
     bool built = false;
     // index arrays
     DevBuf x32, xnorm2, panels, bias, stats;
+    // int8 scan copy (scan_i8.hpp): byte-valued integer corpora with D <= 128, kept NEXT TO the fp16 panels (a batch of
+    // non-integer queries still takes the fp16 scan)
+    DevBuf panels8, bias8;
+    bool i8_ok = false;
+    int i8_cx = 0, i8_ks = 0, i8_disable = 0;
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
@@ -209,6 +215,8 @@ void index_stats(vdb_index_s *h, hipStream_t st) {
     memcpy(&h->maxnorm2, &hs.maxnorm2_bits, 4);
     h->nonfinite = hs.nonfinite != 0;
     h->corpus_int_unscaled = !hs.not_integer && !h->nonfinite && h->absmax <= 2048.f;
+    h->i8_cx = !hs.not_u8 ? 128 : 0;                        // u8 window first (SIFT), else s8
+    h->i8_ok = !h->nonfinite && (!hs.not_u8 || !hs.not_s8) && h->dim <= 128;
     h->sx = 1.f;
     if (!h->corpus_int_unscaled && h->absmax > 0.f && !h->nonfinite) {
         int e;
@@ -259,6 +267,21 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
         VDB_HIP(hipStreamSynchronize(st));
         h->corpus_fp16_exact = hs.not_fp16_exact == 0;
         h->scan_ok = true;
+        h->i8_ok = h->i8_ok && !h->tile16;
+        if (h->i8_ok) {
+            h->i8_ks = D <= 64 ? 2 : 4;
+            h->panels8.reserve((size_t)ntiles * h->i8_ks * 64 * sizeof(int4v));
+            const int64_t t8 = ntiles * h->i8_ks * 64;
+            build_panels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
+                h->x32.as<float>(), n, D, D4, h->i8_ks, ntiles, h->i8_cx, h->panels8.as<int4v>());
+            h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
+            build_bias_i8_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(
+                h->x32.as<float>(), n, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>());
+            VDB_HIP(hipGetLastError());
+            VDB_HIP(hipStreamSynchronize(st));
+        }
+    } else {
+        h->i8_ok = false;
     }
     h->built = true;
 }
@@ -666,6 +689,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     const int64_t nbins = g.nspans * G * (direct_rows ? kBinRows / direct_rows : 1), nsb = (int64_t)g.nchunks * G;
     const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
     const int rescan_cap = std::max(16, k / 2 + 8);
+    // int8 scan for byte-valued corpora: offered to the device-side choice whenever the standard geometry is in use
+    const bool use_i8 = h->i8_ok && !h->i8_disable && !direct_rows && !h->tile16 && h->scan_variant == 0;
     ws.info.reserve(sizeof(QueryBatchInfo));
     ws.qpanels.reserve((size_t)(Qpad / 32) * h->ksteps * 64 * sizeof(half8));
     ws.eps.reserve((size_t)nq * sizeof(float));
@@ -686,7 +711,13 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         const int64_t total = nq * Dm;
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 4096);
         query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
-        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2);
+        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, use_i8 ? 1 : 0);
+        if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
+            ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
+            const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;
+            build_qpanels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
+                dq, nq, Dm, h->i8_ks, Qpad / 32, info, ws.qpanels8.as<int4v>());
+        }
         const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
         if (h->tile16)
             build_qpanels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, h->ksteps / 2, Qpad / 16, info, ws.qpanels.as<half8>());
@@ -722,7 +753,23 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         h->dbg_words = nblocks * 8 * 8;
     }
     timing_mark(h, tslot, 0, st);
-    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows);
+    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows);       // (fp16: returns at once when the int8 scan serves the batch)
+    if (use_i8) {
+        ScanI8Args s8{};
+        s8.panels = h->panels8.as<int4v>();
+        s8.bias8 = h->bias8.as<int32_t>();
+        s8.qpanels = ws.qpanels8.as<int4v>();
+        s8.info = info;
+        s8.bin_m1 = sa.bin_m1; s8.bin_m2 = sa.bin_m2;
+        s8.sb_m1 = sa.sb_m1; s8.sb_m2 = sa.sb_m2; s8.sb_span = sa.sb_span;
+        s8.nspans = g.nspans; s8.Npad = h->Npad; s8.Qpad = Qpad; s8.nq_valid = nq;
+        s8.spans_per_chunk = g.spc; s8.chunk_rem = g.rem; s8.nchunks = g.nchunks;
+        s8.nqtiles = (int)(Qpad / 512);
+        const unsigned grid8 = 8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles;
+        if (h->i8_ks == 2) scan_i8_kernel<2, 4><<<dim3(grid8), dim3(512), 0, st>>>(s8);
+        else scan_i8_kernel<4, 4><<<dim3(grid8), dim3(512), 0, st>>>(s8);
+        VDB_HIP(hipGetLastError());
+    }
     timing_mark(h, tslot, 1, st);
 
     SelectArgs se{};
@@ -948,7 +995,7 @@ int vdb_destroy(vdb_handle h) {
         if (!h) return;
         set_device(h->device);
         (void)hipDeviceSynchronize();
-        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->ivf_offsets, &h->ivf_ids,
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
                          &h->ivf_cnt, &h->ivf_cursor, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_query, &h->ivf_slot_of};
@@ -1150,7 +1197,15 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.metric = h->metric;
         s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
         s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
-                                     h->ws.bytes());
+                                     h->panels8.cap + h->bias8.cap + h->ws.bytes());
+        s.has_i8_copy = h->i8_ok ? 1 : 0;
+        s.scan_dtype = 0;
+        if (h->i8_ok && h->last.last_path == VDB_PATH_MFMA_SCAN && h->ws.info.p) {   // which scan the device chose
+            QueryBatchInfo qi;
+            VDB_HIP(hipDeviceSynchronize());
+            VDB_HIP(hipMemcpy(&qi, h->ws.info.p, sizeof(qi), hipMemcpyDeviceToHost));
+            s.scan_dtype = qi.i8_mode ? 1 : 0;
+        }
         s.nlist = h->nlist;
         s.nprobe = h->nprobe;
         s.last_candidates = s.last_rescan_bins = s.last_fallback_queries = 0;
@@ -1220,6 +1275,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "panel_layout") {   // 0 auto, 1 = 32-row tiles for every D, 2 = p16 for every D (next add)
             if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "panel_layout must be 0, 1 or 2");
             h->layout_override = (int)value;
+        } else if (k == "panel_dtype") {    // 0 auto (int8 scan copy used when corpus and queries allow), 1 = fp16 scan only
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_dtype must be 0 or 1");
+            h->i8_disable = (int)value;
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;

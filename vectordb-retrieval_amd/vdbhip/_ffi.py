@@ -30,6 +30,7 @@ class Stats(Structure):
         ("last_path", c_int32), ("corpus_fp16_exact", c_int32), ("last_nq", c_int64),
         ("last_candidates", c_int64), ("last_rescan_bins", c_int64), ("last_fallback_queries", c_int64),
         ("last_scan_ms", c_float), ("last_total_ms", c_float), ("nlist", c_int32), ("nprobe", c_int32),
+        ("scan_dtype", c_int32), ("has_i8_copy", c_int32), ("last_rows_scanned", c_int64),
     ]
 
     def as_dict(self):
@@ -119,7 +120,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vdb_abi_version() != 1:
+        if lib.vdb_abi_version() != 2:
             raise ImportError("libvdbhip.so ABI version mismatch")
         _lib = lib
     return _lib
