@@ -140,4 +140,79 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
     }
 }
 
+// Same selection for Npad <= 64 * VPL rows (IVF coarse quantizers with nlist <= 2048), with the query's scores held
+// in REGISTERS (row e*64 + lane in v[e]): the 32 bisection steps count with v_cmp + ballot instead of re-reading the
+// scores from LDS and reducing with 6 shuffles per step (the LDS form is LDS-bandwidth bound: 100 us per 10k queries
+// on 1024 centroids).  4 queries per workgroup; LDS holds only the candidate lists.
+template <int KPL, int VPL>
+__global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    if (q >= a.nq) return;
+    int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * a.cand_cap;
+    const int n = (int)a.Npad, k = a.c.k;
+    const float *src = a.scores + (size_t)q * a.Npad;
+    unsigned v[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+        const int i = e * 64 + lane;
+        v[e] = i < n ? sortable_u32(src[i]) : 0xFFFFFFFFu;
+    }
+    unsigned ans = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = ans | ((1u << bit) - 1u);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) cnt += __popcll(__ballot(v[e] <= trial));
+        if (cnt < k) ans |= (1u << bit);
+    }
+    const float that = unsortable_f32(ans) + 2.0f * a.eps[q];
+    bool fb = a.info->force_fallback || !(that < 0.9e38f);
+    const unsigned tkey = sortable_u32(that);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int ncand = 0;
+    if (!fb) {
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) {
+            const int i = e * 64 + lane;
+            const bool hit = i < n && v[e] <= tkey;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = ncand + __popcll(m & lt_mask);
+                if (pos < a.cand_cap) cands[pos] = i;
+            }
+            ncand += __popcll(m);
+        }
+    }
+    if (ncand > a.cand_cap) fb = true;
+    if (fb) {
+        if (lane == 0) {
+            a.fallback[q] = 1;
+            a.fb_list[atomicAdd(a.fb_count, 1)] = (int)q;
+            stat_add(a.stat_counters, q, 2, 1ull);
+        }
+        return;
+    }
+    const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+    WaveTopK<KPL> tk;
+    tk.init(k);
+    for (int base = 0; base < ncand; base += 64) {
+        const int i = base + lane;
+        bool valid = i < ncand;
+        const int64_t row = valid ? (int64_t)cands[i] : 0;
+        valid = valid && row < a.c.N;
+        uint64_t key = ~0ull;
+        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        tk.offer(key, a.c.id_base + row, valid);
+    }
+    const size_t o = (size_t)q * k;
+    write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
+                    a.pids ? a.pids + o : nullptr);
+    if (lane == 0) {
+        a.fallback[q] = 0;
+        stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
+    }
+}
+
 }  // namespace vdb

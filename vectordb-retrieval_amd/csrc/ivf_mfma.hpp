@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void ivf_qrows_kernel(const float *__restrict_
 
 // ---- select over the bins of a query's probed lists ----------------------------------------------------
 struct IvfSelectArgs {
-    const float *bin_m1, *bin_m2;
+    const float *bin_m1, *bin_m2, *bin_m3;
     const float *eps;
     const QueryBatchInfo *info;
     const IvfPlan *plan;
@@ -340,11 +340,13 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
         for (int base_e = 0; base_e < E && !fb; base_e += 64) {
             const int e = base_e + lane;
-            bool cand = false, resc = false;
-            int row0 = 0, row1 = 0;
-            float m1 = 0.f;
+            // an active bin yields: its minimum quad; also its second quad when the second minimum is active but the
+            // third is not; a re-scan of the whole bin when three or more quads are active (or a quad would run past
+            // the end of its list)
+            bool c1 = false, c2 = false, resc = false;
+            int row0 = 0, row1 = 0, crow1 = 0, crow2 = 0;
             if (e < E) {
-                m1 = unsortable_f32(vals[e]);
+                const float m1 = unsortable_f32(vals[e]);
                 if (m1 <= that) {
                     const int p = probe_of(e), ei = e - p_off[p];
                     const int l = p_list[p];
@@ -356,23 +358,30 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     row1 = row0 + a.bt * 16;
                     const int end = a.span_row0[pspan] + a.span_valid[pspan];
                     if (row1 > end) row1 = end;
-                    resc = m2 <= that;
-                    cand = !resc;
-                    if (cand) {   // a candidate is a quad of 4 rows: it must not run past the end of its list
-                        const int crow = row0 + quad_row_offset(__float_as_uint(m1));
-                        if (crow + kQuadRows > end) {
-                            cand = false;
+                    c1 = true;
+                    crow1 = row0 + quad_row_offset(__float_as_uint(m1));
+                    if (m2 <= that) {
+                        if (a.bin_m3[base + ei] <= that) {
                             resc = true;
-                            row0 = crow;
-                            row1 = end;
+                        } else {
+                            c2 = true;
+                            crow2 = row0 + quad_row_offset(__float_as_uint(m2));
                         }
+                    }
+                    if (resc || crow1 + kQuadRows > end || (c2 && crow2 + kQuadRows > end)) {
+                        c1 = c2 = false;
+                        resc = row1 > row0;
                     }
                 }
             }
-            const unsigned long long cm = __ballot(cand), rm = __ballot(resc);
-            if (cand) {
-                const int pos = ncand + __popcll(cm & lt_mask);
-                if (pos < a.cand_cap) cr[pos] = row0 + quad_row_offset(__float_as_uint(m1));
+            const unsigned long long cm1 = __ballot(c1), cm2 = __ballot(c2), rm = __ballot(resc);
+            if (c1) {
+                const int pos = ncand + __popcll(cm1 & lt_mask);
+                if (pos < a.cand_cap) cr[pos] = crow1;
+            }
+            if (c2) {
+                const int pos = ncand + __popcll(cm1) + __popcll(cm2 & lt_mask);
+                if (pos < a.cand_cap) cr[pos] = crow2;
             }
             if (resc) {
                 const int pos = nres + __popcll(rm & lt_mask);
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     rr[2 * pos + 1] = row1;
                 }
             }
-            ncand += __popcll(cm);
+            ncand += __popcll(cm1) + __popcll(cm2);
             nres += __popcll(rm);
         }
         if (ncand > a.cand_cap || nres > a.rescan_cap) fb = true;

@@ -29,6 +29,7 @@ struct ScanArgs {
     const QueryBatchInfo *info;
     float *bin_m1;         // [nspans*2][Qpad]  packed min of each bin
     float *bin_m2;         // [nspans*2][Qpad]  second min of each bin
+    float *bin_m3;         // ITEMS mode only: third-smallest quad minimum of each bin (the re-scan guard, see select_phase)
     float *sb_m1;          // [nchunks*2][Qpad] packed min of each superbin (chunk x lane half)
     float *sb_m2;          // [nchunks*2][Qpad] second-smallest score of the superbin
     int32_t *sb_span;      // [nchunks*2][Qpad] span holding the superbin minimum
@@ -107,9 +108,14 @@ __device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half
 // 3 + 1 + 2 = 6 VALU ops per 4 scores (1.5 per score instead of 3), which takes the VALU off the critical path
 // of the matrix pipe.  A candidate is then a quad (4 rows, re-scored exactly), and the bin's second minimum is
 // the second-smallest QUAD minimum: two close scores inside one quad need no re-scan at all.
-template <int ABL>
+// M3 (IVF items mode): also keep the THIRD-smallest quad minimum m3 (one more med3 per quad).  Both m1 and m2 carry
+// their quad ids, so a bin whose third minimum is above the threshold yields two candidate quads instead of a re-scan
+// of the whole bin: the probed lists of a query are dense in near neighbours and "two close quads in one bin" is
+// common there (0.6-0.9 re-scanned bins per query with the two-minimum guard, a few per hundred with three).
+template <int ABL, bool M3 = false>
 __device__ __forceinline__ void select_phase(const float16v &acc0, const float16v &acc1, float (&m1)[2],
-                                             float (&m2)[2], unsigned idmask, float neg_inf, unsigned id0) {
+                                             float (&m2)[2], unsigned idmask, float neg_inf, unsigned id0,
+                                             float *m3 = nullptr) {
     if (ABL == 1) {
         asm volatile("" ::"v"(acc0), "v"(acc1));
         return;
@@ -119,11 +125,13 @@ __device__ __forceinline__ void select_phase(const float16v &acc0, const float16
         const float q0 = fast_min(fast_min(acc0[4 * g], acc0[4 * g + 1], neg_inf),
                                   fast_min(acc0[4 * g + 2], acc0[4 * g + 3], neg_inf), neg_inf);
         const float v0 = pack_score(q0, idmask, id0 + g);
+        if (M3) m3[0] = __builtin_amdgcn_fmed3f(m2[0], m3[0], v0);
         m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
         m1[0] = fast_min(m1[0], v0, neg_inf);
         const float q1 = fast_min(fast_min(acc1[4 * g], acc1[4 * g + 1], neg_inf),
                                   fast_min(acc1[4 * g + 2], acc1[4 * g + 3], neg_inf), neg_inf);
         const float v1 = pack_score(q1, idmask, id0 + g);
+        if (M3) m3[1] = __builtin_amdgcn_fmed3f(m2[1], m3[1], v1);
         m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
         m1[1] = fast_min(m1[1], v1, neg_inf);
     }
@@ -230,6 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));   // pin the mask in a VGPR (a literal cannot ride in VOP3 next to an SGPR id)
     float m1[2] = {INF, INF}, m2[2] = {INF, INF};   // level 1 (current bin)
+    float m3[2] = {INF, INF};                       // ITEMS mode: third minimum
     float M1[2] = {INF, INF}, M2[2] = {INF, INF};   // level 2 (whole chunk)
     int Ms[2] = {0, 0};
 
@@ -281,6 +290,10 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         for (int cb = 0; cb < 2; ++cb) {
             a.bin_m1[o + cb * cbs] = m1[cb];
             a.bin_m2[o + cb * cbs] = m2[cb];
+            if (ITEMS) {
+                a.bin_m3[o + cb * cbs] = m3[cb];
+                m3[cb] = INF;
+            }
             if (!ITEMS) {
                 M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
                 if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ABL == 4) { asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1)); tb = stamp(); c_mfma += tb - ta; ta = tb; }
                 if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2));
+                select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2), m3);
                 if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
                 // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
-                select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2));
+                select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2), m3);
                 if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
                     flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             __syncthreads();
             if (ABL == 4) { tb = stamp(); c_bar += tb - ta; }
         }
-        select_phase<ABL>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2));  // drain the last tile
+        select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2), m3);  // drain the last tile
         flush_bin(span1 - 1, BPS - 1);
     }
     if (ABL == 4 && a.dbg && lane == 0) {

@@ -126,18 +126,17 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }   // v_med3_i32
 
 // select of one tile: per column block 4 quads of 4 consecutive corpus rows; v = (min of the quad << 6) | quad id
-__device__ __forceinline__ void select_phase_i8(const int16v &acc0, const int16v &acc1, int (&m1)[2], int (&m2)[2],
-                                                unsigned id0) {
+template <int CB>
+__device__ __forceinline__ void select_phase_i8(const int16v (&acc)[CB], int (&m1)[CB], int (&m2)[CB], unsigned id0) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int q0 = imin(imin(acc0[4 * g], acc0[4 * g + 1]), imin(acc0[4 * g + 2], acc0[4 * g + 3]));
-        const int v0 = (int)(((unsigned)q0 << 6) | (id0 + g));
-        m2[0] = imed3(m1[0], m2[0], v0);
-        m1[0] = imin(m1[0], v0);
-        const int q1 = imin(imin(acc1[4 * g], acc1[4 * g + 1]), imin(acc1[4 * g + 2], acc1[4 * g + 3]));
-        const int v1 = (int)(((unsigned)q1 << 6) | (id0 + g));
-        m2[1] = imed3(m1[1], m2[1], v1);
-        m1[1] = imin(m1[1], v1);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int q = imin(imin(acc[cb][4 * g], acc[cb][4 * g + 1]), imin(acc[cb][4 * g + 2], acc[cb][4 * g + 3]));
+            const int v = (int)(((unsigned)q << 6) | (id0 + g));
+            m2[cb] = imed3(m1[cb], m2[cb], v);
+            m1[cb] = imin(m1[cb], v);
+        }
     }
 }
 
@@ -153,24 +152,29 @@ __device__ __forceinline__ void read_phase_i8(const int4v *__restrict__ A_tile, 
     }
 }
 
-template <int KS>
-__device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v (&b0)[KS], const int4v (&b1)[KS],
-                                              const int16v &cin, int16v &acc0, int16v &acc1) {
+template <int KS, int CB>
+__device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v (&bq)[CB][KS], const int16v &cin,
+                                              int16v (&acc)[CB]) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[ks], b0[ks], ks == 0 ? cin : acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[ks], b1[ks], ks == 0 ? cin : acc1, 0, 0, 0);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[ks], bq[cb][ks], ks == 0 ? cin : acc[cb], 0, 0, 0);
 }
 
-// KS: 32-dim k-steps (D padded to 32*KS: 2 or 4); ST: tiles per LDS stage.  8 waves, 2 per SIMD, phase-staggered halves
-// exactly as scan_kernel: the early half runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).
-template <int KS, int ST>
+// KS: 32-dim k-steps (D padded to 32*KS: 2 or 4); ST: tiles per LDS stage; CB: 32-query column blocks per wave (2 ->
+// 512-query tiles as scan_kernel, 4 -> 1024-query tiles: every A fragment read from LDS feeds 4 MFMAs and a stage
+// carries twice the matrix work per barrier).  8 waves, 2 per SIMD, phase-staggered halves exactly as scan_kernel: the
+// early half runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).
+template <int KS, int ST, int CB>
 __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     constexpr int NWAVES = 8, NT = 512, BT = 16;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
     constexpr int SPS = kTilesPerSpan / ST;
+    // tiles of a stage unrolled together: the whole stage for the baseline shape; wider shapes keep the tile loop
+    // rolled (fully unrolled, hipcc keeps several tiles' fragments and bias registers alive and spills hundreds of VGPRs)
+    constexpr int UNR = (ST * CB <= 8) ? ST : 1;
     static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && BT % ST == 0, "bad geometry");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     const int mode = a.info->i8_mode;
@@ -187,24 +191,26 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
     const int chunk = x + 8 * ci;
     if (chunk >= a.nchunks) return;
-    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 32 * CB) + wave * (32 * CB);
     const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
     int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
     const int64_t out_col = q0 + (lane & 31);
     const int32_t *bias = a.bias8 + (mode == 1 ? 0 : a.Npad);
 
-    int4v b0[KS], b1[KS];
+    int4v bq[CB][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        b0[ks] = a.qpanels[((size_t)(q0 / 32 + 0) * KS + ks) * 64 + lane];
-        b1[ks] = a.qpanels[((size_t)(q0 / 32 + 1) * KS + ks) * 64 + lane];
-    }
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KS + ks) * 64 + lane];
     const int nstages = (int)(span1 - span0) * SPS;
     const int INF = (int)kI8Inf;
-    int m1[2] = {INF, INF}, m2[2] = {INF, INF};
-    int M1[2] = {INF, INF}, M2[2] = {INF, INF};
-    int Ms[2] = {0, 0};
+    int m1[CB], m2[CB], M1[CB], M2[CB], Ms[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        m1[cb] = m2[cb] = M1[cb] = M2[cb] = INF;
+        Ms[cb] = 0;
+    }
 
     constexpr int kPieces = kStageVec / 64;
     static_assert(kPieces % NWAVES == 0, "pieces must divide over the waves");
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     auto flush_bin = [&](int64_t span) {
         const size_t o = (size_t)(span * 2 + h) * a.Qpad + out_col;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB; ++cb) {
             a.bin_m1[o + cb * 32] = __int_as_float(m1[cb]);
             a.bin_m2[o + cb * 32] = __int_as_float(m2[cb]);
             M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     stage_bias_store(0);
     __syncthreads();
 
-    if (a.nq_valid > 0 && q0 >= a.nq_valid) {            // all 64 query columns are padding: keep staging + barriers going
+    if (a.nq_valid > 0 && q0 >= a.nq_valid) {            // every query column of this wave is padding: keep staging + barriers going
         for (int st = 0; st < nstages; ++st) {
             if (st + 1 < nstages) {
                 stage_issue(st + 1, (st & 1) ^ 1);
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     }
 
     int4v fr[KS];
-    int16v cin, acc0, acc1;
+    int16v cin, acc[CB];
     if (!late) {
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
@@ -277,13 +283,13 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
             read_phase_i8<KS>(A, B4, fr, cin, lane);
-#pragma unroll
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_phase_i8<KS>(fr, b0, b1, cin, acc0, acc1);
+                mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase_i8(acc0, acc1, m1, m2, (unsigned)(((ts0 + t) % BT) << 2));
+                select_phase_i8<CB>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) << 2));
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS);
@@ -292,35 +298,36 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = (int)(kI8Inf >> 6);   // dummy "previous tile": (x << 6) == "+inf", never wins
-        acc1 = acc0;
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = (int)(kI8Inf >> 6);   // dummy "previous tile": (x << 6) == "+inf", never wins
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
             if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
             const int4v *A = lds_a(buf);
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
-#pragma unroll
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase_i8<KS>(A + t * KS * 64, B4 + t * 8, fr, cin, lane);
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
-                select_phase_i8(acc0, acc1, m1, m2, (unsigned)((tp % BT) << 2));
+                select_phase_i8<CB>(acc, m1, m2, (unsigned)((tp % BT) << 2));
                 if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_phase_i8<KS>(fr, b0, b1, cin, acc0, acc1);
+                mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
-        select_phase_i8(acc0, acc1, m1, m2, (unsigned)((BT - 1) << 2));
+        select_phase_i8<CB>(acc, m1, m2, (unsigned)((BT - 1) << 2));
         flush_bin(span1 - 1);
     }
 
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
         a.sb_m1[so + cb * 32] = __int_as_float(M1[cb]);
         a.sb_m2[so + cb * 32] = __int_as_float(M2[cb]);
         a.sb_span[so + cb * 32] = Ms[cb];

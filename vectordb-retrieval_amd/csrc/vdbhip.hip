@@ -56,13 +56,13 @@ struct ScopedDevBuf : DevBuf {
 };
 
 struct Workspace {
-    DevBuf qpad, qpanels, qpanels8, info, eps, bin_m1, bin_m2, sb_m1, sb_m2, sb_span;
+    DevBuf qpad, qpanels, qpanels8, info, eps, bin_m1, bin_m2, bin_m3, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
-        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
                                &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
                                &stage_i, &dense};
         size_t s = 0;
@@ -70,7 +70,7 @@ struct Workspace {
         return s;
     }
     void release() {
-        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &sb_m1, &sb_m2, &sb_span, &cand,
+        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
                          &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
                          &dense};
         for (auto b : all) b->release();
@@ -90,7 +90,7 @@ struct vdb_index_s {
     // non-integer queries still takes the fp16 scan)
     DevBuf panels8, bias8;
     bool i8_ok = false;
-    int i8_cx = 0, i8_ks = 0, i8_disable = 0;
+    int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
@@ -541,7 +541,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
         VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
         const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 4096)), dim3(256), 0, st>>>(dq, total, info);
+        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0,
                                                           h->maxnorm2);
         const int64_t threads = (Qp / 32) * h->ksteps * 64;
@@ -582,8 +582,18 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         da.pids = pi;
         {
             const int kpl = kpl_for(k);
-            const size_t lds = (size_t)(h->Npad + cand_cap) * 4;
-            DISPATCH_KPL(kpl, (dense_select_kernel<KPL><<<dim3((unsigned)nq), dim3(64), lds, st>>>(da)));
+            if (h->Npad <= 2048 && kpl <= 4) {       // scores in registers, 4 queries per workgroup (dense.hpp)
+                const dim3 g4((unsigned)((nq + 3) / 4));
+                const size_t lds4 = (size_t)4 * cand_cap * 4;
+                if (h->Npad <= 1024) {
+                    DISPATCH_KPL(kpl, (dense_select_reg_kernel<(KPL <= 4 ? KPL : 4), 16><<<g4, dim3(256), lds4, st>>>(da)));
+                } else {
+                    DISPATCH_KPL(kpl, (dense_select_reg_kernel<(KPL <= 4 ? KPL : 4), 32><<<g4, dim3(256), lds4, st>>>(da)));
+                }
+            } else {
+                const size_t lds = (size_t)(h->Npad + cand_cap) * 4;
+                DISPATCH_KPL(kpl, (dense_select_kernel<KPL><<<dim3((unsigned)nq), dim3(64), lds, st>>>(da)));
+            }
             VDB_HIP(hipGetLastError());
         }
         // queries whose candidate list overflowed (or unusable scales): exhaustive exact pass
@@ -709,8 +719,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
     {
         const int64_t total = nq * Dm;
-        const unsigned blocks = (unsigned)std::min<int64_t>((total + 1023) / 1024, 4096);
-        query_stats_kernel<<<dim3(blocks), dim3(256), 0, st>>>(dq, total, info);
+        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info);
         query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, use_i8 ? 1 : 0);
         if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
             ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
@@ -764,10 +773,19 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         s8.sb_m1 = sa.sb_m1; s8.sb_m2 = sa.sb_m2; s8.sb_span = sa.sb_span;
         s8.nspans = g.nspans; s8.Npad = h->Npad; s8.Qpad = Qpad; s8.nq_valid = nq;
         s8.spans_per_chunk = g.spc; s8.chunk_rem = g.rem; s8.nchunks = g.nchunks;
-        s8.nqtiles = (int)(Qpad / 512);
-        const unsigned grid8 = 8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles;
-        if (h->i8_ks == 2) scan_i8_kernel<2, 4><<<dim3(grid8), dim3(512), 0, st>>>(s8);
-        else scan_i8_kernel<4, 4><<<dim3(grid8), dim3(512), 0, st>>>(s8);
+        // i8_variant (tuning, every variant exact): 0 = 512-query tiles / 4-tile stages, 1 = 8-tile stages,
+        // 2 = 1024-query tiles (4 column blocks per wave), 3 = both
+        const int v8 = (Qpad % 1024 == 0) ? h->i8_variant : (h->i8_variant & 1);
+        const int qtile = (v8 & 2) ? 1024 : 512;
+        s8.nqtiles = (int)(Qpad / qtile);
+        const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
+#define VDB_I8(KS_, ST_, CB_) scan_i8_kernel<KS_, ST_, CB_><<<grid8, dim3(512), 0, st>>>(s8)
+        if (h->i8_ks == 2) {
+            switch (v8) { case 1: VDB_I8(2, 8, 2); break; case 2: VDB_I8(2, 4, 4); break; case 3: VDB_I8(2, 8, 4); break; default: VDB_I8(2, 4, 2); }
+        } else {
+            switch (v8) { case 1: VDB_I8(4, 8, 2); break; case 2: VDB_I8(4, 4, 4); break; case 3: VDB_I8(4, 8, 4); break; default: VDB_I8(4, 4, 2); }
+        }
+#undef VDB_I8
         VDB_HIP(hipGetLastError());
     }
     timing_mark(h, tslot, 1, st);
@@ -1278,6 +1296,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "panel_dtype") {    // 0 auto (int8 scan copy used when corpus and queries allow), 1 = fp16 scan only
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_dtype must be 0 or 1");
             h->i8_disable = (int)value;
+        } else if (k == "i8_variant") {
+            if (value < 0 || value > 3) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..3");
+            h->i8_variant = (int)value;
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;
