@@ -266,3 +266,41 @@ def test_row_sharded_ivf_partials_merge_to_unsharded_result(vdb, oracle, metric,
     np.testing.assert_array_equal(I_ref, Io)
     for s in shards + [full]:
         s.close()
+
+
+@pytest.mark.parametrize("metric,window,d", [("l2", "u8", 128), ("ip", "u8", 96), ("l2", "s8", 64), ("l2", "u8", 50)])
+def test_int8_list_scan_bit_exact(vdb, oracle, metric, window, d):
+    """Byte-valued corpora: the list-major scan runs on the int8 copy (scan_i8.hpp, items mode) when the query batch is
+    integer too -- same results as the oracle, as the fp16 list scan and as the exact list scan."""
+    rng = np.random.default_rng(31)
+    n, nq, nlist, k = 150_000, 700, 128, 10
+    off = 0 if window == "u8" else -128
+    X = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(n, d))), 0, 255).astype(np.float32) + off
+    Q = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(nq, d))), 0, 255).astype(np.float32) + off
+    C = X[rng.choice(n, nlist, replace=False)] + rng.uniform(-0.25, 0.25, (nlist, d)).astype(np.float32)
+    idx = vdb.IVFFlatIndex(d, nlist, metric, 0)
+    idx.set_centroids(C)
+    idx.add(X, id_base=7)
+    lor = idx.assignment()
+    for nprobe in (4, 16, 64):
+        idx.set_nprobe(nprobe)
+        D, I = idx.search(Q, k)
+        st = idx.stats()
+        assert st["last_path_name"] == "ivf" and st["has_i8_copy"] == 1 and st["scan_dtype"] == 1, st
+        Do, Io = oracle.ivf_search(X, C, lor, Q, k, nprobe, metric, id_base=7)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+        idx.set_option("panel_dtype", 1)            # fp16 list scan of the same index
+        D1, I1 = idx.search(Q, k)
+        assert idx.stats()["scan_dtype"] == 0
+        idx.set_option("panel_dtype", 0)
+        np.testing.assert_array_equal(I1, I)
+        np.testing.assert_array_equal(D1, D)
+    Q2 = Q.copy()
+    Q2[3, 5] += 0.25                                 # one non-integer value: the batch takes the fp16 scan
+    D2, I2 = idx.search(Q2, k)
+    assert idx.stats()["scan_dtype"] == 0
+    Do2, Io2 = oracle.ivf_search(X, C, lor, Q2, k, 64, metric, id_base=7)
+    np.testing.assert_array_equal(I2, Io2)
+    np.testing.assert_array_equal(D2, Do2)
+    idx.close()

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void ivf_qrows_kernel(const float *__restrict_
                                                         const QueryBatchInfo *__restrict__ info,
                                                         _Float16 *__restrict__ qrows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * Dpad) return;
+    if (i >= nq * Dpad || info->i8_mode) return;
     const int64_t q = i / Dpad;
     const int d = (int)(i - q * Dpad);
     qrows[i] = (_Float16)(d < D ? Q[(size_t)q * D + d] * info->bscale : 0.f);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
             if (cnt < a.k) ans |= (1u << bit);
         }
-        const float that = unsortable_f32(ans) + 2.0f * a.eps[q];
+        const float that = select_threshold(unsortable_f32(ans), a.eps[q], a.info->i8_mode);
         if (!(that < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;

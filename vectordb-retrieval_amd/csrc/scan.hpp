@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
     auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
-    if (!ITEMS && a.info->i8_mode) return;                  // this batch is served by scan_i8_kernel (scan_i8.hpp)
+    if (a.info->i8_mode) return;                            // this batch is served by scan_i8_kernel (scan_i8.hpp)
 
     // ---- block -> (chunk, query tile), XCD aware; or -> IVF work item -----------------------------
     const int tid = threadIdx.x, lane = tid & 63;

@@ -119,6 +119,10 @@ struct ScanI8Args {
     int32_t *sb_span;
     int64_t nspans, Npad, Qpad, nq_valid;
     int spans_per_chunk, chunk_rem, nchunks, nqtiles;
+    // ---- IVF ("items") mode, as ScanArgs: one workgroup = (one inverted list) x (one group of 64*NWAVES query slots) ----
+    float *bin_m3;               // third-smallest quad minimum of each bin
+    const int32_t *item_list, *item_slot0, *item_bin0, *n_items, *list_pspan0, *slot_query;
+    const signed char *qrows;    // [nq][32*KS] int8 query rows cq - q (B fragments are gathered from them)
 };
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -126,14 +130,16 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }   // v_med3_i32
 
 // select of one tile: per column block 4 quads of 4 consecutive corpus rows; v = (min of the quad << 6) | quad id
-template <int CB>
-__device__ __forceinline__ void select_phase_i8(const int16v (&acc)[CB], int (&m1)[CB], int (&m2)[CB], unsigned id0) {
+template <int CB, bool M3 = false>
+__device__ __forceinline__ void select_phase_i8(const int16v (&acc)[CB], int (&m1)[CB], int (&m2)[CB], unsigned id0,
+                                                int *m3 = nullptr) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int q = imin(imin(acc[cb][4 * g], acc[cb][4 * g + 1]), imin(acc[cb][4 * g + 2], acc[cb][4 * g + 3]));
             const int v = (int)(((unsigned)q << 6) | (id0 + g));
+            if (M3) m3[cb] = imed3(m2[cb], m3[cb], v);       // (items mode: third minimum, see scan.hpp select_phase)
             m2[cb] = imed3(m1[cb], m2[cb], v);
             m1[cb] = imin(m1[cb], v);
         }
@@ -163,19 +169,22 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 }
 
 // KS: 32-dim k-steps (D padded to 32*KS: 2 or 4); ST: tiles per LDS stage; CB: 32-query column blocks per wave (2 ->
-// 512-query tiles as scan_kernel, 4 -> 1024-query tiles: every A fragment read from LDS feeds 4 MFMAs and a stage
-// carries twice the matrix work per barrier).  8 waves, 2 per SIMD, phase-staggered halves exactly as scan_kernel: the
-// early half runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).
-template <int KS, int ST, int CB>
-__global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
-    constexpr int NWAVES = 8, NT = 512, BT = 16;
+// 64 queries per wave as scan_kernel, 4 -> 128: every A fragment read from LDS feeds 4 MFMAs and a stage carries twice
+// the matrix work per barrier).  NWAVES waves, 2 per SIMD, phase-staggered halves exactly as scan_kernel: the early half
+// runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).  BT: tiles per level-1 bin; ITEMS: IVF work-item
+// mode (one inverted list x one group of query slots, bins laid out [item][slot][bin], third minimum kept).
+template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false>
+__global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
+    constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
     constexpr int SPS = kTilesPerSpan / ST;
+    constexpr int BPS = kTilesPerSpan / BT;               // level-1 bins per (span, lane half)
     // tiles of a stage unrolled together: the whole stage for the baseline shape; wider shapes keep the tile loop
     // rolled (fully unrolled, hipcc keeps several tiles' fragments and bias registers alive and spills hundreds of VGPRs)
     constexpr int UNR = (ST * CB <= 8) ? ST : 1;
-    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && BT % ST == 0, "bad geometry");
+    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && kTilesPerSpan % BT == 0 && BT % ST == 0, "bad geometry");
+    static_assert(!ITEMS || CB == 2, "items mode: 64 slots per wave");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     const int mode = a.info->i8_mode;
     if (!mode) return;                                    // this batch is served by the fp16 scan
@@ -185,30 +194,58 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const bool late = wave >= NWAVES / 2;
-    const int b = blockIdx.x;
-    const int x = b & 7, j = b >> 3;
-    const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
-    const int chunk = x + 8 * ci;
-    if (chunk >= a.nchunks) return;
-    const int64_t q0 = (int64_t)qt * (NWAVES * 32 * CB) + wave * (32 * CB);
-    const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
-    int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
-    if (span1 > a.nspans) span1 = a.nspans;
-    const int64_t out_col = q0 + (lane & 31);
+    const bool late = (NWAVES >= 2) && (wave >= NWAVES / 2);
+    int chunk = 0;
+    int64_t q0, span0, span1, out_pitch, out_col;
+    size_t bin_base = 0;
+    if (ITEMS) {
+        const int it = blockIdx.x;
+        if (it >= *a.n_items) return;
+        const int l = a.item_list[it];
+        span0 = a.list_pspan0[l];
+        span1 = a.list_pspan0[l + 1];
+        q0 = (int64_t)a.item_slot0[it] + wave * 64;
+        out_pitch = NWAVES * 64;
+        out_col = wave * 64 + (lane & 31);
+        bin_base = (size_t)a.item_bin0[it];
+    } else {
+        const int b = blockIdx.x;
+        const int x = b & 7, j = b >> 3;
+        const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
+        chunk = x + 8 * ci;
+        if (chunk >= a.nchunks) return;
+        q0 = (int64_t)qt * (NWAVES * 32 * CB) + wave * (32 * CB);
+        span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
+        span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
+        if (span1 > a.nspans) span1 = a.nspans;
+        out_pitch = a.Qpad;
+        out_col = q0 + (lane & 31);
+    }
     const int32_t *bias = a.bias8 + (mode == 1 ? 0 : a.Npad);
 
     int4v bq[CB][KS];
+    if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+        for (int cb = 0; cb < CB; ++cb) {
+            const int qa = a.slot_query[q0 + cb * 32 + (lane & 31)];
+            const int4v *ra = reinterpret_cast<const int4v *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (32 * KS)) + h;
+            const int4v zero = {0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KS + ks) * 64 + lane];
+            for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = qa < 0 ? zero : ra[ks * 2];
+        }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KS + ks) * 64 + lane];
+    }
     const int nstages = (int)(span1 - span0) * SPS;
+    const int nb_item = (int)(span1 - span0) * 2 * BPS;    // ITEMS: bins per query slot in this item
     const int INF = (int)kI8Inf;
-    int m1[CB], m2[CB], M1[CB], M2[CB], Ms[CB];
+    int m1[CB], m2[CB], m3[CB], M1[CB], M2[CB], Ms[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-        m1[cb] = m2[cb] = M1[cb] = M2[cb] = INF;
+        m1[cb] = m2[cb] = m3[cb] = M1[cb] = M2[cb] = INF;
         Ms[cb] = 0;
     }
 
@@ -244,15 +281,24 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
         for (int i = 0; i < kBiasLoads; ++i)
             if (tid + i * NT < ST * 32) lds_b(buf)[tid + i * NT] = stage_b[i];
     };
-    auto flush_bin = [&](int64_t span) {
-        const size_t o = (size_t)(span * 2 + h) * a.Qpad + out_col;
+    // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]; ITEMS: [item][slot][bin]
+    auto flush_bin = [&](int64_t span, int bt) {
+        const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
+                                     (size_t)(((span - span0) * 2 + h) * BPS + bt)
+                               : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
+        const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            a.bin_m1[o + cb * 32] = __int_as_float(m1[cb]);
-            a.bin_m2[o + cb * 32] = __int_as_float(m2[cb]);
-            M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
-            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
-            M1[cb] = imin(M1[cb], m1[cb]);
+            a.bin_m1[o + cb * cbs] = __int_as_float(m1[cb]);
+            a.bin_m2[o + cb * cbs] = __int_as_float(m2[cb]);
+            if (ITEMS) {
+                a.bin_m3[o + cb * cbs] = __int_as_float(m3[cb]);
+                m3[cb] = INF;
+            } else {
+                M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
+                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+                M1[cb] = imin(M1[cb], m1[cb]);
+            }
             m1[cb] = INF;
             m2[cb] = INF;
         }
@@ -262,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
     stage_bias_store(0);
     __syncthreads();
 
-    if (a.nq_valid > 0 && q0 >= a.nq_valid) {            // every query column of this wave is padding: keep staging + barriers going
+    if (!ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid) {   // every query column of this wave is padding: keep staging + barriers going
         for (int st = 0; st < nstages; ++st) {
             if (st + 1 < nstages) {
                 stage_issue(st + 1, (st & 1) ^ 1);
@@ -289,10 +335,10 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase_i8<CB>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) << 2));
+                select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) << 2), m3);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS);
+            if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
@@ -312,8 +358,8 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase_i8<KS>(A + t * KS * 64, B4 + t * 8, fr, cin, lane);
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
-                select_phase_i8<CB>(acc, m1, m2, (unsigned)((tp % BT) << 2));
-                if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan);
+                select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)((tp % BT) << 2), m3);
+                if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
             }
@@ -321,9 +367,10 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
-        select_phase_i8<CB>(acc, m1, m2, (unsigned)((BT - 1) << 2));
-        flush_bin(span1 - 1);
+        select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)((BT - 1) << 2), m3);
+        flush_bin(span1 - 1, BPS - 1);
     }
+    if (ITEMS) return;
 
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);
 #pragma unroll
@@ -332,6 +379,86 @@ __global__ __launch_bounds__(512, 2) void scan_i8_kernel(ScanI8Args a) {
         a.sb_m2[so + cb * 32] = __int_as_float(M2[cb]);
         a.sb_span[so + cb * 32] = Ms[cb];
     }
+}
+
+// ---- IVF build / per-batch helpers for the int8 copy --------------------------------------------------------------
+// int8 panels over the list-padded panel space (ivf_mfma.hpp: span_row0 / span_valid map a panel span to its rows)
+__global__ __launch_bounds__(256) void ivf_build_panels_i8_kernel(const float *__restrict__ X, int D, int D4, int ks32,
+                                                                  int64_t ntiles, int cx,
+                                                                  const int32_t *__restrict__ span_row0,
+                                                                  const int32_t *__restrict__ span_valid,
+                                                                  int4v *__restrict__ panels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ks32);
+    const int64_t tile = tk / ks32;
+    if (tile >= ntiles) return;
+    const int rho = lane & 31, kh = lane >> 5;
+    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+    const int64_t span = tile / kTilesPerSpan;
+    const int t = (int)(tile - span * kTilesPerSpan);
+    const int local = h * kBinRows + t * 16 + r;
+    const bool valid = local < span_valid[span];
+    const int64_t row = (int64_t)span_row0[span] + local;
+    const int d0 = ks * 32 + kh * 16;
+    int4v out;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int d = d0 + 4 * w + b;
+            int v = 0;
+            if (valid && d < D) v = (int)X[(size_t)row * D4 + d] - cx;
+            word |= ((unsigned)v & 0xffu) << (8 * b);
+        }
+        out[w] = (int)word;
+    }
+    panels[gid] = out;
+}
+
+// bias8[w][panel row] over the panel space (P spans of 512 rows); padding rows get kI8PadBias
+__global__ __launch_bounds__(256) void ivf_build_bias_i8_kernel(const float *__restrict__ X, int64_t nspans, int D, int D4,
+                                                                int metric, const int32_t *__restrict__ span_row0,
+                                                                const int32_t *__restrict__ span_valid,
+                                                                int32_t *__restrict__ bias8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nspans * kSpanRows;
+    if (i >= total) return;
+    const int64_t span = i / kSpanRows;
+    const int local = (int)(i - span * kSpanRows);
+    if (local >= span_valid[span]) {
+        bias8[i] = kI8PadBias;
+        bias8[total + i] = kI8PadBias;
+        return;
+    }
+    const int64_t row = (int64_t)span_row0[span] + local;
+    long long n2 = 0, s1 = 0;
+    for (int d = 0; d < D; ++d) {
+        const long long v = (long long)X[(size_t)row * D4 + d];
+        n2 += v * v;
+        s1 += v;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const long long cq = w == 0 ? 127 : -1;
+        const long long b = metric == 0 ? ((n2 - 2 * cq * s1) >> 1) : -cq * s1;
+        bias8[(size_t)w * total + i] = (int32_t)(b + kI8Offset);
+    }
+}
+
+// int8 copy of the query rows, [nq][32*ks32] = cq - q; the items-mode scan gathers its B fragments from it
+__global__ __launch_bounds__(256) void ivf_qrows_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
+                                                           const QueryBatchInfo *__restrict__ info,
+                                                           signed char *__restrict__ qrows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int mode = info->i8_mode;
+    if (i >= nq * Dpad || !mode) return;
+    const int64_t q = i / Dpad;
+    const int d = (int)(i - q * Dpad);
+    const int cq = mode == 1 ? 127 : -1;
+    qrows[i] = (signed char)(d < D ? cq - (int)Q[(size_t)q * D + d] : 0);
 }
 
 }  // namespace vdb

@@ -1218,7 +1218,8 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
                                      h->panels8.cap + h->bias8.cap + h->ws.bytes());
         s.has_i8_copy = h->i8_ok ? 1 : 0;
         s.scan_dtype = 0;
-        if (h->i8_ok && h->last.last_path == VDB_PATH_MFMA_SCAN && h->ws.info.p) {   // which scan the device chose
+        if (h->i8_ok && h->ws.info.p &&
+            (h->last.last_path == VDB_PATH_MFMA_SCAN || (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma))) {   // which scan the device chose
             QueryBatchInfo qi;
             VDB_HIP(hipDeviceSynchronize());
             VDB_HIP(hipMemcpy(&qi, h->ws.info.p, sizeof(qi), hipMemcpyDeviceToHost));
