@@ -76,6 +76,7 @@ typedef struct vdb_stats_s {
     int32_t scan_dtype;        /* arithmetic of the last MFMA scan: 0 = fp16 (f32 accumulate), 1 = int8 (i32 accumulate) */
     int32_t has_i8_copy;       /* 1 if the index holds the int8 scan copy (byte-valued integer corpus, D <= 128) */
     int64_t last_rows_scanned; /* IVF: (query, row) pairs scanned by the last search (rows of the probed lists) */
+    int64_t upload_blocks;     /* row blocks the last vdb_add / vdb_ivf_add streamed through the pinned staging buffers */
 } vdb_stats_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -89,7 +90,9 @@ int vdb_destroy(vdb_handle h);
 
 /* replaces index.add(vectors) (exact_search.py:39; modular.py:124-130 keeps the raw matrix):
  * uploads n rows (row-major float32, host memory) and builds the scan copy.  Row i gets id
- * id_base + i (row-sharded corpora pass their shard offset).  One-shot: a second call replaces the corpus. */
+ * id_base + i (row-sharded corpora pass their shard offset).  One-shot: a second call replaces the corpus.
+ * The rows are streamed in blocks (option "upload_block_mb", default 64 MiB) through two pinned staging buffers, so
+ * x_host may be a memory-mapped file far larger than host RAM comfortably holds (dataset.py:376-471, 1001-1052). */
 int vdb_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
 /* same, rows already in device memory of the handle's GPU */
 int vdb_add_device(vdb_handle h, const float *x_dev, int64_t n, int64_t id_base, void *stream);

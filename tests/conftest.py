@@ -35,3 +35,11 @@ def oracle():
 
     c_oracle.build()
     return c_oracle
+
+
+@pytest.fixture(scope="session")
+def vdb():
+    """The product package (GPU tests only: importing it does not touch the GPU, using it does)."""
+    import vdbhip
+
+    return vdbhip

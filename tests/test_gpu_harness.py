@@ -111,3 +111,38 @@ def test_local_file_datasets_fvecs_and_npy(oracle, tmp_path):
         assert res["ivf"]["recall@10"] == 1.0          # nprobe = nlist: IVF degenerates to brute force
     with pytest.raises(ValueError, match="needs local files"):
         harness.run_benchmark(dict(base, datasets=[{"name": "sift1m"}]))
+
+
+def test_row_block_ingestion_from_a_memmap_larger_than_the_staging_buffer(vdb, oracle, tmp_path):
+    """vdb_add / vdb_ivf_add stream the host rows in blocks through two pinned staging buffers (dataset.py:376-471 keeps
+    its corpora as np.memmap): with a 1 MiB block a 24 MB memory-mapped corpus goes up in 24+ blocks, and the index is
+    the same as the one built from the in-memory array."""
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((61_237, 100)).astype(np.float32)      # D = 100: rows are re-pitched to 100 floats on the device
+    Q = rng.standard_normal((300, 100)).astype(np.float32)
+    path = tmp_path / "corpus.npy"
+    np.save(path, X)
+    mm = np.load(path, mmap_mode="r")
+    idx = vdb.FlatIndex(100, "l2", 0)
+    idx.set_option("upload_block_mb", 1)
+    idx.add(mm, id_base=11)
+    rows_per_block = (1 << 20) // (100 * 4)
+    assert idx.stats()["upload_blocks"] == -(-len(X) // rows_per_block) == 24
+    D, I = idx.search(Q, 10)
+    Do, Io = oracle.knn(X, Q, 10, "l2", id_base=11)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    idx.close()
+    C = X[rng.choice(len(X), 64, replace=False)].copy()
+    ivf = vdb.IVFFlatIndex(100, 64, "l2", 0)
+    ivf.set_centroids(C)
+    ivf.set_option("upload_block_mb", 1)
+    ivf.add(mm)
+    assert ivf.stats()["upload_blocks"] > 20
+    np.testing.assert_array_equal(ivf.assignment(), oracle.ivf_assign(C, X, "l2"))
+    ivf.set_nprobe(8)
+    D, I = ivf.search(Q, 10)
+    Do, Io = oracle.ivf_search(X, C, ivf.assignment(), Q, 10, 8, "l2")
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    ivf.close()

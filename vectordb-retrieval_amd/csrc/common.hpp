@@ -41,6 +41,9 @@ __device__ __forceinline__ void stat_add(unsigned long long *counters, long long
     atomicAdd(&counters[(size_t)(q & (kStatShards - 1)) * kStatStride + idx], v);
 }
 constexpr size_t kSmallBytes = 64 + (size_t)kStatShards * kStatStride * 8;   // ws.small: fb_count + sharded counters
+// ws.small layout: [0,4) fb_count | [16,64) QueryBatchInfo of the current batch | [64, ...) sharded statistics.  The
+// first 64 bytes are cleared with ONE memset per batch (each memset is a ~4 us dispatch of its own).
+constexpr size_t kInfoOffset = 16;
 
 struct IndexStats {       // filled on device by the corpus-prep kernels
     unsigned absmax_bits; // bits of max |x|
@@ -64,7 +67,9 @@ struct QueryBatchInfo {   // per search call, device resident
     int force_fallback;   // scales unusable (non-finite input / overflow): every query takes the exhaustive path
     int not_u8, not_s8;   // query values outside the integers 0..255 / -128..127
     int i8_mode;          // 0: fp16 scan.  1 / 2: int8 scan (scan_i8.hpp), queries in the u8 / s8 window
+    unsigned done_blocks; // workgroups of query_stats_kernel that have contributed (the last one finalises the scales)
 };
+static_assert(sizeof(QueryBatchInfo) + 16 <= 64, "QueryBatchInfo must fit the first 64 bytes of ws.small");
 
 // ---- int8 scan copy (scan_i8.hpp) ---------------------------------------------------------------------------------
 // Integer corpora whose values fit one byte (SIFT descriptors are uint8) get a second scan copy for

@@ -69,6 +69,11 @@ struct DenseSelectArgs {
     int64_t *I;
     double *pkeys;             // partial rows [nq][k]
     int64_t *pids;
+    int set_only;              // final mode, register kernel: the caller only uses the SET of the k nearest rows (IVF coarse
+                               // quantizer: which lists to probe).  Rows whose approximate score is below tau - 2 eps are in
+                               // the exact top-k for certain (tau - eps bounds the exact k-th distance from below) and are
+                               // written as they are; only the band |score - tau| <= 2 eps is re-scored exactly, and its best
+                               // k - #certain rows complete the set.  I holds the set in no particular order, D is not meaningful.
 };
 
 // one wave (= one workgroup) per query; LDS: Npad sortable scores + cand_cap row ids (<= ~40 KiB)
@@ -167,22 +172,30 @@ __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a
         for (int e = 0; e < VPL; ++e) cnt += __popcll(__ballot(v[e] <= trial));
         if (cnt < k) ans |= (1u << bit);
     }
-    const float that = unsortable_f32(ans) + 2.0f * a.eps[q];
+    const float tau = unsortable_f32(ans), e2 = 2.0f * a.eps[q];
+    const float that = tau + e2;
     bool fb = a.info->force_fallback || !(that < 0.9e38f);
     const unsigned tkey = sortable_u32(that);
+    // set-only mode: scores strictly below tau - 2 eps are certain members; the bound is lowered by another 1e-6 |tau| so
+    // that the rounding of the subtraction cannot raise it (a lower bound only moves rows into the re-scored band)
+    const unsigned ckey = a.set_only ? sortable_u32(tau - e2 - 1.0e-6f * fabsf(tau)) : 0u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int ncand = 0;
+    int ncand = 0, ncert = 0;
     if (!fb) {
 #pragma unroll
         for (int e = 0; e < VPL; ++e) {
             const int i = e * 64 + lane;
-            const bool hit = i < n && v[e] <= tkey;
-            const unsigned long long m = __ballot(hit);
+            const bool in = i < n && v[e] <= tkey;
+            const bool cert = a.set_only && in && v[e] < ckey && i < a.c.N;
+            const bool hit = in && !cert;
+            const unsigned long long m = __ballot(hit), mc = __ballot(cert);
             if (hit) {
                 const int pos = ncand + __popcll(m & lt_mask);
                 if (pos < a.cand_cap) cands[pos] = i;
             }
+            if (cert) a.I[(size_t)q * k + ncert + __popcll(mc & lt_mask)] = a.c.id_base + i;   // (< k of them: tau is in the band)
             ncand += __popcll(m);
+            ncert += __popcll(mc);
         }
     }
     if (ncand > a.cand_cap) fb = true;
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a
     }
     const float *qptr = a.c.Q + (size_t)q * a.c.D4;
     WaveTopK<KPL> tk;
-    tk.init(k);
+    tk.init(k - ncert);
     for (int base = 0; base < ncand; base += 64) {
         const int i = base + lane;
         bool valid = i < ncand;
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a
         if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
         tk.offer(key, a.c.id_base + row, valid);
     }
-    const size_t o = (size_t)q * k;
+    const size_t o = (size_t)q * k + ncert;
     write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
                     a.pids ? a.pids + o : nullptr);
     if (lane == 0) {

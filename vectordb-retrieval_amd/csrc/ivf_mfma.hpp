@@ -72,6 +72,7 @@ struct IvfPlan {          // device-resident scalars written by ivf_plan_kernel
     int32_t n_slots;
     int32_t n_bins;
     int32_t overflow;     // plan did not fit the buffers: the batch takes the exact list scan
+    unsigned long long rows_scanned;   // (query, row) pairs of this batch: sum over lists of probes x rows
 };
 
 // per-list probe counts.  Workgroup-local LDS histogram first (nlist <= kIvfLdsLists), then one global atomic
@@ -110,14 +111,17 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
                                                         int bps, int max_items, int max_slots, int max_bins,
                                                         int32_t *__restrict__ slot_off, int32_t *__restrict__ list_item0,
                                                         int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
-                                                        int32_t *__restrict__ item_bin0, IvfPlan *plan) {
+                                                        int32_t *__restrict__ item_bin0, IvfPlan *plan,
+                                                        const int64_t *__restrict__ offsets) {
     __shared__ int s_g[1024], s_b[1024];
     __shared__ int s_items, s_bins, s_overflow;
+    __shared__ unsigned long long s_rows;
     const int tid = threadIdx.x;
     if (tid == 0) {
         s_items = 0;
         s_bins = 0;
         s_overflow = 0;
+        s_rows = 0;
     }
     __syncthreads();
     for (int l0 = 0; l0 < nlist; l0 += 1024) {
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
         if (l < nlist) {
             const int c = cnt[l];
             const int spans = list_pspan0[l + 1] - list_pspan0[l];
+            if (c > 0) atomicAdd(&s_rows, (unsigned long long)c * (unsigned long long)(offsets[l + 1] - offsets[l]));
             if (c > 0 && spans > 0) {
                 g = (c + group - 1) / group;
                 bins_per_item = spans * 2 * bps;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
         plan->n_slots = slots;
         plan->n_bins = bins;
         plan->overflow = overflow;
+        plan->rows_scanned = s_rows;
     }
 }
 
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restr
         if (rank[u] >= 0) {
             const int64_t l = probes[i];
             slot = slot_off[l] + rank[u] + (use_lds ? ivf_hist[l] : 0);
-            slot_query[slot] = (int32_t)(i / nprobe);
+            slot_query[slot] = (int32_t)(i / nprobe) + 1;     // (0 = padding slot)
         }
         slot_of[i] = slot;
     }

@@ -138,6 +138,38 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const float *__restrict
 }
 
 // ---- queries ----------------------------------------------------------------------------------------
+// scales of a query batch, chosen by ONE thread once the statistics are complete (the last workgroup of
+// query_stats_kernel): power-of-two query scale, scan score scale, fallback flag, fp16 / int8 scan choice.
+struct FinalizeArgs {
+    float sx;                  // corpus scale of the fp16 copy
+    int metric;
+    int corpus_int_unscaled;
+    float maxnorm2;
+    int corpus_i8;             // the index holds an int8 scan copy and this search may use it (0 = fp16 scan only)
+};
+__device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &f) {
+    const float amax = __uint_as_float(__hip_atomic_load(&info->absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int not_integer = __hip_atomic_load(&info->not_integer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nonfinite = __hip_atomic_load(&info->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int not_u8 = __hip_atomic_load(&info->not_u8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int not_s8 = __hip_atomic_load(&info->not_s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float fm = (f.metric == 0) ? 2.f : 1.f;
+    float sq = 1.f;
+    const bool int_ok = f.corpus_int_unscaled && !not_integer && fm * amax <= 2048.f;
+    if (!int_ok && amax > 0.f && amax <= 3.0e38f) {
+        int e;
+        frexpf(fm * amax, &e);          // fm*amax = m * 2^e, m in [0.5,1)
+        sq = ldexpf(1.f, 14 - e);       // fm*amax*sq in [8192, 16384)
+    }
+    info->sq = sq;
+    info->cs = sq * f.sx;
+    info->bscale = -fm * sq;
+    const float top = sq * f.sx * f.maxnorm2;
+    info->force_fallback = (nonfinite || !(top < 1.0e30f) || !(sq * f.sx > 1.0e-30f)) ? 1 : 0;
+    info->i8_mode = 0;
+    if (f.corpus_i8 && !nonfinite) info->i8_mode = !not_u8 ? 1 : (!not_s8 ? 2 : 0);
+}
+
 // Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics per workgroup (same
 // addresses for everybody) stays a few hundred operations -- 1250 workgroups cost 21 us on a 5 MB batch, the read
 // itself takes 1-2.
@@ -145,7 +177,7 @@ inline unsigned query_stats_blocks(int64_t total) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 256));
 }
 __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restrict__ Q, int64_t total,
-                                                          QueryBatchInfo *info) {
+                                                          QueryBatchInfo *info, FinalizeArgs fin) {
     __shared__ float s_max[4];
     __shared__ int s_flags[4];
     float amax = 0.f;
@@ -181,29 +213,11 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         if (flags & 2) atomic_set_flag(&info->not_integer);
         if (flags & 6) atomic_set_flag(&info->not_u8);
         if (flags & 10) atomic_set_flag(&info->not_s8);
+        // the workgroup that arrives last sees every contribution (atomics execute in L2) and fixes the scales: no
+        // separate one-thread kernel (a ~5 us dispatch) between the statistics and their consumers
+        __threadfence();
+        if (atomicAdd(&info->done_blocks, 1u) == gridDim.x - 1) query_finalize(info, fin);
     }
-}
-
-// one thread: choose the power-of-two query scale for this batch
-// corpus_i8: the index holds an int8 scan copy and this search may use it (0 = fp16 scan only)
-__global__ void query_finalize_kernel(QueryBatchInfo *info, float sx, int metric, int corpus_int_unscaled,
-                                      float maxnorm2, int corpus_i8 = 0) {
-    const float amax = __uint_as_float(info->absmax_bits);
-    const float f = (metric == 0) ? 2.f : 1.f;
-    float sq = 1.f;
-    const bool int_ok = corpus_int_unscaled && !info->not_integer && f * amax <= 2048.f;
-    if (!int_ok && amax > 0.f && amax <= 3.0e38f) {
-        int e;
-        frexpf(f * amax, &e);           // f*amax = m * 2^e, m in [0.5,1)
-        sq = ldexpf(1.f, 14 - e);       // f*amax*sq in [8192, 16384)
-    }
-    info->sq = sq;
-    info->cs = sq * sx;
-    info->bscale = -f * sq;
-    const float top = sq * sx * maxnorm2;
-    info->force_fallback = (info->nonfinite || !(top < 1.0e30f) || !(sq * sx > 1.0e-30f)) ? 1 : 0;
-    info->i8_mode = 0;
-    if (corpus_i8 && !info->nonfinite) info->i8_mode = !info->not_u8 ? 1 : (!info->not_s8 ? 2 : 0);
 }
 
 // fp16 B-fragment panels of the query batch + padded float32 copy for the refine kernel.

@@ -46,7 +46,7 @@ struct ScanArgs {
     const int32_t *item_bin0;    // [items] first level-1 bin of the item's output block
     const int32_t *n_items;      // [1]
     const int32_t *list_pspan0;  // [nlist+1] panel spans of every list (lists are padded to whole spans)
-    const int32_t *slot_query;   // [slots] query of every slot (-1 = padding)
+    const int32_t *slot_query;   // [slots] query + 1 of every slot (0 = padding)
     const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
     unsigned long long *dbg;     // ABL == 4 (diagnostic build): per-wave cycle sums {head, mfma, select, barrier, total, late}
 };
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     // ---- B fragments: resident for the whole chunk ------------------------------------------------
     half8 b0[KSTEPS], b1[KSTEPS];
     if (ITEMS) {  // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's query row
-        const int qa = a.slot_query[q0 + (lane & 31)], qb = a.slot_query[q0 + 32 + (lane & 31)];
+        const int qa = a.slot_query[q0 + (lane & 31)] - 1, qb = a.slot_query[q0 + 32 + (lane & 31)] - 1;
         const half8 *ra = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (16 * KSTEPS)) + h;
         const half8 *rb = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qb < 0 ? 0 : qb) * (16 * KSTEPS)) + h;
         half8 zero;

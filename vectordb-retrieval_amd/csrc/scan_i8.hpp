@@ -6,7 +6,7 @@
 // per-row integer bias, and an integer select: per quad  min3 + min, v_lshl_or (t' << 6 | quad id), med3 + min.
 // The packed keys are stored as float bit patterns (normal positive floats ordered like the integers), so the select
 // kernels of scan.hpp read them unchanged.  Which of the two scans serves a batch is decided ON THE DEVICE
-// (QueryBatchInfo.i8_mode, set by query_finalize_kernel from the query statistics): both kernels are enqueued and the
+// (QueryBatchInfo.i8_mode, set by query_finalize (prep.hpp) from the query statistics): both kernels are enqueued and the
 // one that is not needed returns at once -- vdb_search_device stays asynchronous.
 #pragma once
 #include "common.hpp"
@@ -123,6 +123,7 @@ struct ScanI8Args {
     float *bin_m3;               // third-smallest quad minimum of each bin
     const int32_t *item_list, *item_slot0, *item_bin0, *n_items, *list_pspan0, *slot_query;
     const signed char *qrows;    // [nq][32*KS] int8 query rows cq - q (B fragments are gathered from them)
+    int abl_no_bins;             // -DVDB_ABLATIONS builds only (timing, WRONG results): skip the level-1 bin stores
 };
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
     if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int qa = a.slot_query[q0 + cb * 32 + (lane & 31)];
+            const int qa = a.slot_query[q0 + cb * 32 + (lane & 31)] - 1;      // (0 = padding slot)
             const int4v *ra = reinterpret_cast<const int4v *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (32 * KS)) + h;
             const int4v zero = {0, 0, 0, 0};
 #pragma unroll
@@ -289,8 +290,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
         const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            a.bin_m1[o + cb * cbs] = __int_as_float(m1[cb]);
-            a.bin_m2[o + cb * cbs] = __int_as_float(m2[cb]);
+#ifdef VDB_ABLATIONS
+            if (!a.abl_no_bins)
+#endif
+            {
+                a.bin_m1[o + cb * cbs] = __int_as_float(m1[cb]);
+                a.bin_m2[o + cb * cbs] = __int_as_float(m2[cb]);
+            }
             if (ITEMS) {
                 a.bin_m3[o + cb * cbs] = __int_as_float(m3[cb]);
                 m3[cb] = INF;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vdbhip.h"
@@ -55,6 +56,9 @@ struct ScopedDevBuf : DevBuf {
     ~ScopedDevBuf() { release(); }
 };
 
+struct Workspace;
+inline QueryBatchInfo *batch_info(Workspace &ws);
+
 struct Workspace {
     DevBuf qpad, qpanels, qpanels8, info, eps, bin_m1, bin_m2, bin_m3, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
@@ -77,6 +81,10 @@ struct Workspace {
     }
 };
 
+inline QueryBatchInfo *batch_info(Workspace &ws) {        // inside ws.small (common.hpp, kInfoOffset)
+    return reinterpret_cast<QueryBatchInfo *>(ws.small.as<char>() + kInfoOffset);
+}
+
 }  // namespace
 
 struct vdb_index_s {
@@ -94,10 +102,18 @@ struct vdb_index_s {
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
     bool nonfinite = false, corpus_int_unscaled = false, corpus_fp16_exact = false, scan_ok = false;
+    // row-block ingestion: two pinned staging buffers (upload_rows)
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    int upload_block_mb = 0;                 // option "upload_block_mb": staging block size (0 = default 64 MiB)
+    int64_t last_upload_blocks = 0;          // blocks of the last host upload (vdb_stats: upload_blocks)
     // options
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
     bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
+    bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
+                                             // not their order or distances (dense.hpp, DenseSelectArgs.set_only)
     // per-search
     Workspace ws;
     vdb_stats_t last{};
@@ -197,6 +213,72 @@ void launch_merge(const MergeArgs &a, int64_t max_slots, hipStream_t st) {
 constexpr double kBinBudget = 6.0 * 1024.0 * 1024.0 * 1024.0;   // bytes of level-1 bin arrays per search pass
 constexpr int64_t kDenseMaxRows = 15360;   // dense small-corpus path: one query's scores fit the default 64 KiB of LDS
 
+// ---- row-block ingestion ---------------------------------------------------------------------------
+// Host rows reach the device in blocks through TWO pinned staging buffers: block b is copied into pinned memory by
+// host threads (this is where a memory-mapped corpus is paged in) while block b-1 is still in flight on the copy
+// engine, so a 38 GB shard never has more than two blocks of host staging behind it -- the reference keeps its corpora
+// as np.memmap for the same reason (src/benchmark/dataset.py:376-471, 1001-1052).  dst rows are D4 floats apart (D4 >=
+// D, the tail must already be zero).
+constexpr size_t kUploadBlockBytes = (size_t)64 << 20;
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const size_t per = (bytes / hw + 4095) & ~(size_t)4095;
+    if (bytes < ((size_t)8 << 20) || hw == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t off = per; off < bytes; off += per)
+        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, std::min(per, bytes - off)); });
+    memcpy(dst, src, std::min(per, bytes));
+    for (auto &t : th) t.join();
+}
+
+void upload_rows(vdb_index_s *h, float *dst, int D4, const float *src, int64_t n, int D, hipStream_t st) {
+    h->last_upload_blocks = 0;
+    if (n <= 0) return;
+    const size_t row_bytes = (size_t)D * 4;
+    const size_t block_bytes = h->upload_block_mb > 0 ? (size_t)h->upload_block_mb << 20 : kUploadBlockBytes;
+    const int64_t rows_per_block = std::max<int64_t>(1, (int64_t)(block_bytes / row_bytes));
+    const size_t need = (size_t)std::min<int64_t>(rows_per_block, n) * row_bytes;
+    if (h->pin_bytes < need) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            h->pin[i] = nullptr;
+        }
+        h->pin_bytes = 0;
+        if (hipHostMalloc(&h->pin[0], need, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc(&h->pin[1], need, hipHostMallocDefault) == hipSuccess) {
+            h->pin_bytes = need;
+        } else {                         // no pinned memory to be had: one pageable copy (the HIP runtime stages it itself)
+            for (int i = 0; i < 2; ++i) {
+                if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+                h->pin[i] = nullptr;
+            }
+            (void)hipGetLastError();
+            VDB_HIP(hipMemcpy2DAsync(dst, (size_t)D4 * 4, src, row_bytes, row_bytes, (size_t)n, hipMemcpyHostToDevice, st));
+            VDB_HIP(hipStreamSynchronize(st));
+            h->last_upload_blocks = 1;
+            return;
+        }
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!h->pin_ev[i]) VDB_HIP(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+    int64_t b = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += rows_per_block, ++b) {
+        const int64_t rows = std::min<int64_t>(rows_per_block, n - r0);
+        const int buf = (int)(b & 1);
+        if (b >= 2) VDB_HIP(hipEventSynchronize(h->pin_ev[buf]));       // the copy that last used this buffer is done
+        parallel_memcpy(h->pin[buf], src + (size_t)r0 * D, (size_t)rows * row_bytes);
+        VDB_HIP(hipMemcpy2DAsync(dst + (size_t)r0 * D4, (size_t)D4 * 4, h->pin[buf], row_bytes, row_bytes, (size_t)rows,
+                                 hipMemcpyHostToDevice, st));
+        VDB_HIP(hipEventRecord(h->pin_ev[buf], st));
+    }
+    VDB_HIP(hipStreamSynchronize(st));
+    h->last_upload_blocks = b;
+}
+
 // ---- index build ---------------------------------------------------------------------------------
 // exact row norms + corpus statistics of h->x32 (N rows) -> scales of the fp16 scan copy
 void index_stats(vdb_index_s *h, hipStream_t st) {
@@ -245,8 +327,11 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     }
     h->x32.reserve((size_t)n * D4 * sizeof(float));
     if (D4 != D) VDB_HIP(hipMemsetAsync(h->x32.p, 0, (size_t)n * D4 * sizeof(float), st));
-    VDB_HIP(hipMemcpy2DAsync(h->x32.p, (size_t)D4 * 4, x_dev_or_host, (size_t)D * 4, (size_t)D * 4, (size_t)n,
-                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (on_device)
+        VDB_HIP(hipMemcpy2DAsync(h->x32.p, (size_t)D4 * 4, x_dev_or_host, (size_t)D * 4, (size_t)D * 4, (size_t)n,
+                                 hipMemcpyDeviceToDevice, st));
+    else
+        upload_rows(h, h->x32.as<float>(), D4, x_dev_or_host, n, D, st);
     index_stats(h, st);
     const bool dims_ok = D <= 4096;
     if (dims_ok && !h->nonfinite) {
@@ -532,18 +617,15 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     if (use_dense) {
         const int64_t Qp = (nq + 63) / 64 * 64;
         const int cand_cap = std::max(128, 2 * k + 64);
-        ws.info.reserve(sizeof(QueryBatchInfo));
         ws.qpanels.reserve((size_t)(Qp / 32) * h->ksteps * 64 * sizeof(half8));
         ws.eps.reserve((size_t)nq * sizeof(float));
         ws.dense.reserve((size_t)Qp * h->Npad * sizeof(float));
         ws.fallback.reserve((size_t)nq * sizeof(int32_t));
         ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
-        QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
-        VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
+        QueryBatchInfo *info = batch_info(ws);          // (zeroed with fb_count above)
         const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info);
-        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0,
-                                                          h->maxnorm2);
+        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
+            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, 0});
         const int64_t threads = (Qp / 32) * h->ksteps * 64;
         build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(
             dq, nq, Dm, D4, h->ksteps, Qp / 32, info, ws.qpanels.as<half8>());
@@ -580,6 +662,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         da.I = I;
         da.pkeys = pk;
         da.pids = pi;
+        da.set_only = (h->set_only && D != nullptr) ? 1 : 0;
         {
             const int kpl = kpl_for(k);
             if (h->Npad <= 2048 && kpl <= 4) {       // scores in registers, 4 queries per workgroup (dense.hpp)
@@ -608,24 +691,30 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         fa.count_ptr = fb_count;
         fa.S = (int)S;
         fa.rows_per_split = (h->N + S - 1) / S;
-        fa.pkeys = ws.pkeys.as<double>();
-        fa.pids = ws.pids.as<int64_t>();
-        launch_refine_full(fa, 1024, st);
-        MergeArgs ma{};
-        ma.pkeys = fa.pkeys;
-        ma.pids = fa.pids;
-        ma.part_stride = k;
-        ma.slot_stride = S * k;
-        ma.nparts = (int)S;
-        ma.k = k;
-        ma.metric = h->metric;
-        ma.qlist = da.fb_list;
-        ma.count_ptr = fb_count;
-        ma.D = D;
-        ma.I = I;
-        ma.okeys = pk;
-        ma.oids = pi;
-        launch_merge(ma, 256, st);
+        if (S == 1 && D) {       // one split: the exhaustive pass writes the final rows itself, nothing to merge
+            fa.D = D;
+            fa.I = I;
+            launch_refine_full(fa, 1024, st);
+        } else {
+            fa.pkeys = ws.pkeys.as<double>();
+            fa.pids = ws.pids.as<int64_t>();
+            launch_refine_full(fa, 1024, st);
+            MergeArgs ma{};
+            ma.pkeys = fa.pkeys;
+            ma.pids = fa.pids;
+            ma.part_stride = k;
+            ma.slot_stride = S * k;
+            ma.nparts = (int)S;
+            ma.k = k;
+            ma.metric = h->metric;
+            ma.qlist = da.fb_list;
+            ma.count_ptr = fb_count;
+            ma.D = D;
+            ma.I = I;
+            ma.okeys = pk;
+            ma.oids = pi;
+            launch_merge(ma, 256, st);
+        }
         timing_mark(h, tslot, 2, st);
         h->last.last_path = VDB_PATH_MFMA_SCAN;
         return;
@@ -701,7 +790,6 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     const int rescan_cap = std::max(16, k / 2 + 8);
     // int8 scan for byte-valued corpora: offered to the device-side choice whenever the standard geometry is in use
     const bool use_i8 = h->i8_ok && !h->i8_disable && !direct_rows && !h->tile16 && h->scan_variant == 0;
-    ws.info.reserve(sizeof(QueryBatchInfo));
     ws.qpanels.reserve((size_t)(Qpad / 32) * h->ksteps * 64 * sizeof(half8));
     ws.eps.reserve((size_t)nq * sizeof(float));
     ws.bin_m1.reserve((size_t)nbins * Qpad * sizeof(float));
@@ -715,12 +803,11 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     ws.fallback.reserve((size_t)nq * sizeof(int32_t));
     ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
 
-    QueryBatchInfo *info = ws.info.as<QueryBatchInfo>();
-    VDB_HIP(hipMemsetAsync(info, 0, sizeof(QueryBatchInfo), st));
+    QueryBatchInfo *info = batch_info(ws);              // (zeroed with fb_count above)
     {
         const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info);
-        query_finalize_kernel<<<dim3(1), dim3(1), 0, st>>>(info, h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, use_i8 ? 1 : 0);
+        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
+            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, use_i8 ? 1 : 0});
         if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
             ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
             const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;
@@ -775,7 +862,10 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         s8.spans_per_chunk = g.spc; s8.chunk_rem = g.rem; s8.nchunks = g.nchunks;
         // i8_variant (tuning, every variant exact): 0 = 512-query tiles / 4-tile stages, 1 = 8-tile stages,
         // 2 = 1024-query tiles (4 column blocks per wave), 3 = both
-        const int v8 = (Qpad % 1024 == 0) ? h->i8_variant : (h->i8_variant & 1);
+#ifdef VDB_ABLATIONS
+        s8.abl_no_bins = (h->i8_variant & 4) ? 1 : 0;
+#endif
+        const int v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 3) : (h->i8_variant & 1);
         const int qtile = (v8 & 2) ? 1024 : 512;
         s8.nqtiles = (int)(Qpad / qtile);
         const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
@@ -1020,6 +1110,10 @@ int vdb_destroy(vdb_handle h) {
         for (auto b : all) b->release();
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
+        }
         for (auto e : h->ev_scan) (void)hipEventDestroy(e);
         for (auto e : h->ev_total) (void)hipEventDestroy(e);
         delete h;
@@ -1217,12 +1311,20 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
                                      h->panels8.cap + h->bias8.cap + h->ws.bytes());
         s.has_i8_copy = h->i8_ok ? 1 : 0;
+        s.upload_blocks = h->last_upload_blocks;
+        s.last_rows_scanned = 0;
+        if (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma && h->ivf_plan.p) {   // (of the last batch of the call)
+            IvfPlan pl;
+            VDB_HIP(hipDeviceSynchronize());
+            VDB_HIP(hipMemcpy(&pl, h->ivf_plan.p, sizeof(pl), hipMemcpyDeviceToHost));
+            s.last_rows_scanned = (int64_t)pl.rows_scanned;
+        }
         s.scan_dtype = 0;
-        if (h->i8_ok && h->ws.info.p &&
+        if (h->i8_ok && h->ws.small.p &&
             (h->last.last_path == VDB_PATH_MFMA_SCAN || (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma))) {   // which scan the device chose
             QueryBatchInfo qi;
             VDB_HIP(hipDeviceSynchronize());
-            VDB_HIP(hipMemcpy(&qi, h->ws.info.p, sizeof(qi), hipMemcpyDeviceToHost));
+            VDB_HIP(hipMemcpy(&qi, batch_info(h->ws), sizeof(qi), hipMemcpyDeviceToHost));
             s.scan_dtype = qi.i8_mode ? 1 : 0;
         }
         s.nlist = h->nlist;
@@ -1297,8 +1399,15 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "panel_dtype") {    // 0 auto (int8 scan copy used when corpus and queries allow), 1 = fp16 scan only
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_dtype must be 0 or 1");
             h->i8_disable = (int)value;
+        } else if (k == "upload_block_mb") {   // staging block of the row-block ingestion (0 = default 64 MiB)
+            if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "upload_block_mb out of range");
+            h->upload_block_mb = (int)value;
         } else if (k == "i8_variant") {
+#ifdef VDB_ABLATIONS
+            if (value < 0 || value > 7) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..7");     // +4: no bin stores (timing only)
+#else
             if (value < 0 || value > 3) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..3");
+#endif
             h->i8_variant = (int)value;
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
