@@ -3,6 +3,7 @@ every symbol include/vdbhip.h declares (no compute calls without a GPU)."""
 from __future__ import annotations
 
 import ctypes
+import os
 import json
 import re
 from pathlib import Path
@@ -202,3 +203,56 @@ def test_harness_warmup_and_latency_summary():
     s = latency_stats([1.0, 2.0, 3.0, 4.0])
     assert s["mean"] == 2.5 and s["median"] == 2.5 and s["min"] == 1.0 and s["max"] == 4.0
     assert s["p95"] == pytest.approx(np.percentile([1, 2, 3, 4], 95))
+
+
+def test_bench_multi_gpu_launcher_fails_loudly_without_the_gpus():
+    """`python bench.py --gpus N` without a torchrun environment starts the ranks itself -- and refuses, before any GPU
+    call, when the node has fewer than N GPUs (instead of silently measuring one GPU and reporting it as N)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "needs 64 GPUs" in (r.stderr + r.stdout)
+    # a rank environment that disagrees with --gpus is refused as well
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_bench_reads_real_sift_files_when_present(tmp_path, monkeypatch):
+    """real sift_base / sift_query / sift_groundtruth under $VDBHIP_DATA are used (with the
+    CORRECT .fvecs reader) instead of the synthetic SIFT1M-shaped data."""
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from vdbhip import io
+
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 219, size=(500, 128)).astype(np.float32)
+    Q = rng.integers(0, 219, size=(20, 128)).astype(np.float32)
+    G = rng.integers(0, 500, size=(20, 100)).astype(np.int32)
+    d = tmp_path / "sift"
+    d.mkdir()
+    io.write_fvecs(d / "sift_base.fvecs", X)
+    io.write_fvecs(d / "sift_query.fvecs", Q)
+    io.write_ivecs(d / "sift_groundtruth.ivecs", G)
+    monkeypatch.delenv("VDBHIP_DATA", raising=False)
+    assert bench.real_sift() is None
+    monkeypatch.setenv("VDBHIP_DATA", str(tmp_path))
+    Xr, Qr, Gr, where = bench.real_sift()
+    np.testing.assert_array_equal(Xr, X)
+    np.testing.assert_array_equal(Qr, Q)
+    np.testing.assert_array_equal(Gr, G)
+    assert where == str(d)
+
+
+def test_golden_manifest_holds_the_published_ivf_point(golden_dir):
+    import json
+
+    pub = json.loads((golden_dir / "manifest.json").read_text())["published_points"]["random_ivf_flat"]
+    assert pub["ivf_flat"]["recall@10"] == 0.410546875 and pub["exact"]["recall@10"] == 1.0
+    assert pub["index_type"] == "IVF100,Flat" and pub["nprobe"] == 10 and pub["config_seed"] == 42

@@ -70,10 +70,9 @@ struct DenseSelectArgs {
     double *pkeys;             // partial rows [nq][k]
     int64_t *pids;
     int set_only;              // final mode, register kernel: the caller only uses the SET of the k nearest rows (IVF coarse
-                               // quantizer: which lists to probe).  Rows whose approximate score is below tau - 2 eps are in
-                               // the exact top-k for certain (tau - eps bounds the exact k-th distance from below) and are
-                               // written as they are; only the band |score - tau| <= 2 eps is re-scored exactly, and its best
-                               // k - #certain rows complete the set.  I holds the set in no particular order, D is not meaningful.
+                               // quantizer: which lists to probe), so candidates that are certainly among them skip the
+                               // float64 re-scoring (dense_select_reg_kernel).  I then holds the set in no particular
+                               // order and D is not meaningful.
 };
 
 // one wave (= one workgroup) per query; LDS: Npad sortable scores + cand_cap row ids (<= ~40 KiB)
@@ -146,56 +145,74 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
 }
 
 // Same selection for Npad <= 64 * VPL rows (IVF coarse quantizers with nlist <= 2048), with the query's scores held
-// in REGISTERS (row e*64 + lane in v[e]): the 32 bisection steps count with v_cmp + ballot instead of re-reading the
-// scores from LDS and reducing with 6 shuffles per step (the LDS form is LDS-bandwidth bound: 100 us per 10k queries
-// on 1024 centroids).  4 queries per workgroup; LDS holds only the candidate lists.
+// in REGISTERS (row e*64 + lane in v[e]) and a cheaper threshold.  The LDS form above bisects for the exact k-th smallest
+// score tau: 32 passes over all Npad scores, LDS-bandwidth bound (100 us per 10k queries on 1024 centroids); doing the
+// same passes on registers with v_cmp + ballot is bound by the CU's one scalar unit instead (58 us).  Any U >= tau is
+// a valid threshold (every true neighbour has an approximate score <= tau + 2 eps <= U + 2 eps), so here every lane
+// first keeps the M smallest of its VPL scores and U = the k-th smallest of those 64*M values (they are distinct rows,
+// so U >= tau; equal to tau unless more than M of the k best fall on one lane).  The bisection then costs M compares
+// per step instead of VPL, and the few extra rows U lets through are re-scored in lanes that would idle anyway.
+// 4 queries per workgroup; LDS holds only the candidate lists.
 template <int KPL, int VPL>
 __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
+    constexpr int M = KPL <= 1 ? 2 : (2 * KPL <= VPL ? 2 * KPL : VPL);     // 64*M >= 2k: k <= 64*KPL
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     if (q >= a.nq) return;
-    int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * a.cand_cap;
+    int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * 2 * a.cand_cap;      // rows | their approximate keys
+    unsigned *ckeys = reinterpret_cast<unsigned *>(cands + a.cand_cap);
     const int n = (int)a.Npad, k = a.c.k;
     const float *src = a.scores + (size_t)q * a.Npad;
     unsigned v[VPL];
+    float sv[VPL];                                  // (all loads in flight before the first use: see select_kernel, scan.hpp)
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) sv[e] = src[min(e * 64 + lane, n - 1)];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sv[e]));
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) v[e] = (e * 64 + lane < n) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
+    unsigned low[M];                                // the M smallest of this lane, ascending
+#pragma unroll
+    for (int j = 0; j < M; ++j) low[j] = 0xFFFFFFFFu;
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
-        const int i = e * 64 + lane;
-        v[e] = i < n ? sortable_u32(src[i]) : 0xFFFFFFFFu;
+        unsigned x = v[e];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const unsigned t = min(low[j], x);
+            x = max(low[j], x);
+            low[j] = t;
+        }
     }
     unsigned ans = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned trial = ans | ((1u << bit) - 1u);
         int cnt = 0;
 #pragma unroll
-        for (int e = 0; e < VPL; ++e) cnt += __popcll(__ballot(v[e] <= trial));
+        for (int j = 0; j < M; ++j) cnt += __popcll(__ballot(low[j] <= trial));
         if (cnt < k) ans |= (1u << bit);
     }
-    const float tau = unsortable_f32(ans), e2 = 2.0f * a.eps[q];
-    const float that = tau + e2;
+    const float e2 = 2.0f * a.eps[q];
+    const float that = unsortable_f32(ans) + e2;
     bool fb = a.info->force_fallback || !(that < 0.9e38f);
     const unsigned tkey = sortable_u32(that);
-    // set-only mode: scores strictly below tau - 2 eps are certain members; the bound is lowered by another 1e-6 |tau| so
-    // that the rounding of the subtraction cannot raise it (a lower bound only moves rows into the re-scored band)
-    const unsigned ckey = a.set_only ? sortable_u32(tau - e2 - 1.0e-6f * fabsf(tau)) : 0u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int ncand = 0, ncert = 0;
+    int ncand = 0;
     if (!fb) {
 #pragma unroll
         for (int e = 0; e < VPL; ++e) {
             const int i = e * 64 + lane;
-            const bool in = i < n && v[e] <= tkey;
-            const bool cert = a.set_only && in && v[e] < ckey && i < a.c.N;
-            const bool hit = in && !cert;
-            const unsigned long long m = __ballot(hit), mc = __ballot(cert);
+            const bool hit = i < n && v[e] <= tkey;
+            const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int pos = ncand + __popcll(m & lt_mask);
-                if (pos < a.cand_cap) cands[pos] = i;
+                if (pos < a.cand_cap) {
+                    cands[pos] = i;
+                    ckeys[pos] = v[e];
+                }
             }
-            if (cert) a.I[(size_t)q * k + ncert + __popcll(mc & lt_mask)] = a.c.id_base + i;   // (< k of them: tau is in the band)
             ncand += __popcll(m);
-            ncert += __popcll(mc);
         }
     }
     if (ncand > a.cand_cap) fb = true;
@@ -206,6 +223,37 @@ __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a
             stat_add(a.stat_counters, q, 2, 1ull);
         }
         return;
+    }
+    // Set-only mode (which lists to probe): the candidates hold every row with an approximate score <= tau, so the
+    // exact tau is the k-th smallest candidate key (a bisection over ~k values).  tau - eps bounds the exact k-th
+    // distance from below, hence a row scoring below tau - 2 eps is among the k nearest for certain and is written out
+    // as it is; only the band around tau is re-scored in float64, and its best k - #certain rows complete the set.
+    int ncert = 0;
+    if (a.set_only && a.D && ncand > k) {
+        unsigned t2 = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = t2 | ((1u << bit) - 1u);
+            int cnt = 0;
+            for (int base = 0; base < ncand; base += 64)
+                cnt += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= trial));
+            if (cnt < k) t2 |= (1u << bit);
+        }
+        const float tau = unsortable_f32(t2);
+        const unsigned ckey = sortable_u32(tau - e2 - 1.0e-6f * fabsf(tau));   // (lowered a little more: rounding of the subtraction)
+        int nband = 0;
+        for (int base = 0; base < ncand; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < ncand;
+            const int row = valid ? cands[i] : 0;
+            const bool cert = valid && ckeys[i] < ckey && row < a.c.N;
+            const bool band = valid && !cert;
+            const unsigned long long mc = __ballot(cert), mb = __ballot(band);
+            if (cert) a.I[(size_t)q * k + ncert + __popcll(mc & lt_mask)] = a.c.id_base + row;     // (< k of them: tau is in the band)
+            if (band) cands[nband + __popcll(mb & lt_mask)] = row;      // compacted in place: nband <= base
+            ncert += __popcll(mc);
+            nband += __popcll(mb);
+        }
+        ncand = nband;
     }
     const float *qptr = a.c.Q + (size_t)q * a.c.D4;
     WaveTopK<KPL> tk;

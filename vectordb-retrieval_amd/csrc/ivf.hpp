@@ -64,6 +64,103 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     if (c == 0) ids[r] = id_base + src;
 }
 
+// ---- CSR build on the device: stable counting sort of the rows by list ---------------------------------------------
+// perm = rows grouped by list, ascending row number inside a list (the layout every result depends on is deterministic),
+// offsets = exclusive prefix of the list sizes.  Rows are cut into chunks of `chunk_rows`:
+//   csr_hist      per-chunk histogram of the lists (LDS), written as chunk_hist[chunk][list]
+//   csr_colscan   per list: exclusive scan over the chunks (in place) + the list total
+//   csr_offsets   exclusive scan of the totals (int64)
+//   csr_scatter   one wave per chunk walks its rows in order, 64 at a time: lanes holding the same list get consecutive
+//                 positions behind the chunk's base and the rows already placed (LDS counter per list)
+// The host loop it replaces (two serial passes over N with random access) dominated IVF builds beyond a few million rows
+// and ran once per k-means iteration.  nlist <= kCsrMaxLists (the per-list counters live in LDS).
+constexpr int kCsrMaxLists = 8192;
+
+__global__ __launch_bounds__(256) void csr_hist_kernel(const int64_t *__restrict__ assign, int64_t n, int nlist,
+                                                       int chunk_rows, int32_t *__restrict__ chunk_hist,
+                                                       int32_t *__restrict__ bad) {
+    extern __shared__ int csr_lds[];
+    for (int l = threadIdx.x; l < nlist; l += 256) csr_lds[l] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(n, r0 + chunk_rows);
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+        const int64_t l = assign[i];
+        if (l < 0 || l >= nlist) *bad = 1;
+        else atomicAdd(&csr_lds[l], 1);
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < nlist; l += 256) chunk_hist[(size_t)blockIdx.x * nlist + l] = csr_lds[l];
+}
+
+__global__ __launch_bounds__(256) void csr_colscan_kernel(int32_t *__restrict__ chunk_hist, int nchunks, int nlist,
+                                                          int32_t *__restrict__ total) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlist) return;
+    int run = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int v = chunk_hist[(size_t)c * nlist + l];
+        chunk_hist[(size_t)c * nlist + l] = run;
+        run += v;
+    }
+    total[l] = run;
+}
+
+__global__ __launch_bounds__(1024) void csr_offsets_kernel(const int32_t *__restrict__ total, int nlist,
+                                                           int64_t *__restrict__ offsets) {
+    __shared__ long long s_v[1024];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int l0 = 0; l0 < nlist; l0 += 1024) {
+        const int l = l0 + tid;
+        const long long v = l < nlist ? total[l] : 0;
+        s_v[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const long long t = tid >= o ? s_v[tid - o] : 0;
+            __syncthreads();
+            s_v[tid] += t;
+            __syncthreads();
+        }
+        if (l < nlist) offsets[l] = s_base + s_v[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_base += s_v[1023];
+        __syncthreads();
+    }
+    if (tid == 0) offsets[nlist] = s_base;
+}
+
+__global__ __launch_bounds__(64) void csr_scatter_kernel(const int64_t *__restrict__ assign, int64_t n, int nlist,
+                                                         int chunk_rows, const int32_t *__restrict__ chunk_base,
+                                                         const int64_t *__restrict__ offsets, int32_t *__restrict__ perm) {
+    extern __shared__ int csr_lds[];          // rows of this chunk already placed, per list
+    const int lane = threadIdx.x;
+    for (int l = lane; l < nlist; l += 64) csr_lds[l] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = min(n, r0 + chunk_rows);
+    const int32_t *cb = chunk_base + (size_t)blockIdx.x * nlist;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int64_t base = r0; base < r1; base += 64) {
+        const int64_t row = base + lane;
+        const int64_t lraw = row < r1 ? assign[row] : -1;
+        const bool valid = lraw >= 0 && lraw < nlist;           // (rows without a list were flagged by csr_hist: the host throws)
+        const int l = valid ? (int)lraw : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {                                        // one round per distinct list among the 64 rows
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lv = __shfl(l, leader);
+            const unsigned long long m = __ballot(valid && l == lv);
+            const int placed = csr_lds[lv];                   // (wave-uniform address: broadcast read)
+            if (valid && l == lv) perm[offsets[lv] + cb[lv] + placed + __popcll(m & lt_mask)] = (int32_t)row;
+            if (lane == leader) csr_lds[lv] = placed + __popcll(m);
+            todo &= ~m;
+        }
+    }
+}
+
 // ---- k-means update: centroid = mean of its points, float64 accumulation in list order (deterministic) ---
 // one wave per centroid; lane d handles dims d, d+64, ...
 __global__ __launch_bounds__(256) void centroid_update_kernel(const float *__restrict__ x, const int32_t *__restrict__ perm,

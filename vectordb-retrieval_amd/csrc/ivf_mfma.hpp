@@ -327,18 +327,33 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
     };
     int ncand = 0, nres = 0;
     if (!fb) {
+        unsigned low0 = 0xFFFFFFFFu, low1 = 0xFFFFFFFFu;     // the two smallest keys this lane has seen
         for (int e = lane; e < E; e += 64) {
             const int p = probe_of(e);
             const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
-            vals[e] = sortable_u32(a.bin_m1[base + (e - p_off[p])]);
+            const unsigned key = sortable_u32(a.bin_m1[base + (e - p_off[p])]);
+            vals[e] = key;
+            low1 = min(low1, max(low0, key));
+            low0 = min(low0, key);
         }
         unsigned ans = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned trial = ans | ((1u << bit) - 1u);
-            int cnt = 0;
-            for (int e = lane; e < E; e += 64) cnt += (vals[e] <= trial) ? 1 : 0;
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-            if (cnt < a.k) ans |= (1u << bit);
+        if (a.k <= 64) {
+            // Threshold from the lanes' two smallest keys: the k-th smallest of these <= 128 distinct bins is >= the k-th
+            // smallest bin minimum tau (equal unless three of the k best bins share a lane), and any U >= tau is a valid
+            // threshold.  32 steps of two compares + ballots instead of 32 passes over all E entries in LDS.
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned trial = ans | ((1u << bit) - 1u);
+                const int cnt = __popcll(__ballot(low0 <= trial)) + __popcll(__ballot(low1 <= trial));
+                if (cnt < a.k) ans |= (1u << bit);
+            }
+        } else {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned trial = ans | ((1u << bit) - 1u);
+                int cnt = 0;
+                for (int e = lane; e < E; e += 64) cnt += (vals[e] <= trial) ? 1 : 0;
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                if (cnt < a.k) ans |= (1u << bit);
+            }
         }
         const float that = select_threshold(unsortable_f32(ans), a.eps[q], a.info->i8_mode);
         if (!(that < 0.9e38f)) fb = true;

@@ -170,11 +170,11 @@ __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &
     if (f.corpus_i8 && !nonfinite) info->i8_mode = !not_u8 ? 1 : (!not_s8 ? 2 : 0);
 }
 
-// Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics per workgroup (same
-// addresses for everybody) stays a few hundred operations -- 1250 workgroups cost 21 us on a 5 MB batch, the read
-// itself takes 1-2.
+// Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics + fence per workgroup
+// (same addresses for everybody) stays a few dozen operations -- 1250 workgroups cost 21 us on a 5 MB batch, the
+// read itself takes 1-2.
 inline unsigned query_stats_blocks(int64_t total) {
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 256));
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 512));
 }
 __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restrict__ Q, int64_t total,
                                                           QueryBatchInfo *info, FinalizeArgs fin) {
@@ -189,13 +189,20 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
     };
     const int64_t nvec = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) ? total / 4 : 0;     // float4 body, scalar tail
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {          // four loads in flight per thread (the kernel is latency bound)
+        const float4 v0 = Q4[i], v1 = Q4[i + stride], v2 = Q4[i + 2 * stride], v3 = Q4[i + 3 * stride];
+        see(v0.x); see(v0.y); see(v0.z); see(v0.w);
+        see(v1.x); see(v1.y); see(v1.z); see(v1.w);
+        see(v2.x); see(v2.y); see(v2.z); see(v2.w);
+        see(v3.x); see(v3.y); see(v3.z); see(v3.w);
+    }
+    for (; i < nvec; i += stride) {
         const float4 v = Q4[i];
         see(v.x); see(v.y); see(v.z); see(v.w);
     }
-    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x)
-        see(Q[i]);
+    for (int64_t j = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) see(Q[j]);
     for (int o = 32; o > 0; o >>= 1) {
         amax = fmaxf(amax, __shfl_xor(amax, o));
         flags |= __shfl_xor(flags, o);
@@ -213,9 +220,12 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         if (flags & 2) atomic_set_flag(&info->not_integer);
         if (flags & 6) atomic_set_flag(&info->not_u8);
         if (flags & 10) atomic_set_flag(&info->not_s8);
-        // the workgroup that arrives last sees every contribution (atomics execute in L2) and fixes the scales: no
-        // separate one-thread kernel (a ~5 us dispatch) between the statistics and their consumers
-        __threadfence();
+        // The workgroup that arrives last fixes the scales: no separate one-thread kernel (a ~5 us dispatch) between the
+        // statistics and their consumers.  Every contribution is an agent-scope atomic (performed at the coherence point,
+        // never parked in this XCD's L2) and query_finalize reads with agent-scope atomic loads, so waiting for this
+        // thread's own atomics (vmcnt) before the counter bump orders them -- a __threadfence() here writes back the whole
+        // L2 and cost 3-7 us per workgroup (MI355X_MICROARCH.md, "Valid forms": agent atomics on both sides).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(&info->done_blocks, 1u) == gridDim.x - 1) query_finalize(info, fin);
     }
 }

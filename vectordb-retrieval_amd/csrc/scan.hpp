@@ -664,11 +664,16 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const int dbps = a.direct_rows ? kBinRows / a.direct_rows : 0;       // direct mode: bins per (span, lane group)
     const int nsb = a.direct_rows ? (int)a.nspans * a.groups * dbps : a.nchunks * a.groups;
     unsigned v[VPL];
+    // All VPL loads are issued before any is used: a load under `s < nsb ? .. : ..` becomes a branch with its own
+    // s_waitcnt vmcnt(0) (hipcc also sinks a clamped-index load back under the condition), i.e. VPL serialised memory
+    // round trips per wave.  The opaque asm makes every loaded value "used" unconditionally.
+    float sv[VPL];
 #pragma unroll
-    for (int e = 0; e < VPL; ++e) {
-        const int s = e * 64 + lane;
-        v[e] = (s < nsb) ? sortable_u32(a.sb_m1[(size_t)s * a.Qpad + q]) : 0xFFFFFFFFu;
-    }
+    for (int e = 0; e < VPL; ++e) sv[e] = a.sb_m1[(size_t)min(e * 64 + lane, nsb - 1) * a.Qpad + q];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sv[e]));
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) v[e] = (e * 64 + lane < nsb) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
     // k-th smallest by bisection from the top bit
     unsigned ans = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -806,11 +811,13 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     const int nsb = a.nchunks * a.groups;
     if (part < 3) s_cnt[wave][qi][part] = 0;
     unsigned v[V];
+    float sv[V];                                    // (all loads in flight before the first use: see select_kernel)
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        const int s = e * LPQ + part;
-        v[e] = (s < nsb) ? sortable_u32(a.sb_m1[(size_t)s * a.Qpad + q]) : 0xFFFFFFFFu;
-    }
+    for (int e = 0; e < V; ++e) sv[e] = a.sb_m1[(size_t)min(e * LPQ + part, nsb - 1) * a.Qpad + q];
+#pragma unroll
+    for (int e = 0; e < V; ++e) asm volatile("" : "+v"(sv[e]));
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = (e * LPQ + part < nsb) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
     unsigned ans = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned trial = ans | ((1u << bit) - 1u);

@@ -108,6 +108,25 @@ __global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__re
     qpanels[gid] = out;
 }
 
+// row-major int8 copy for the list refine (refine.hpp, RefineCommon.X8): rows[row][pitch] = x - cx, bytes beyond D hold
+// -cx (x = 0).  One thread per (row, 4-byte word).
+__global__ __launch_bounds__(256) void build_rows_i8_kernel(const float *__restrict__ X, int64_t N, int D, int D4, int pitch,
+                                                            int cx, signed char *__restrict__ rows) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = pitch / 4;
+    const int64_t row = gid / wpr;
+    if (row >= N) return;
+    const int w = (int)(gid - row * wpr);
+    unsigned word = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int d = 4 * w + b;
+        const int v = (d < D ? (int)X[(size_t)row * D4 + d] : 0) - cx;
+        word |= ((unsigned)v & 0xffu) << (8 * b);
+    }
+    reinterpret_cast<unsigned *>(rows)[gid] = word;
+}
+
 // ---- the scan ------------------------------------------------------------------------------------------------------
 struct ScanI8Args {
     const int4v *panels;     // [ntiles][KS][64]

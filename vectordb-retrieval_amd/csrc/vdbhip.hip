@@ -96,7 +96,8 @@ struct vdb_index_s {
     DevBuf x32, xnorm2, panels, bias, stats;
     // int8 scan copy (scan_i8.hpp): byte-valued integer corpora with D <= 128, kept NEXT TO the fp16 panels (a batch of
     // non-integer queries still takes the fp16 scan)
-    DevBuf panels8, bias8;
+    DevBuf panels8, bias8, rows8;            // rows8: row-major int8 copy for the list refine (refine.hpp, X8)
+    int rows8_pitch = 0;
     bool i8_ok = false;
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
@@ -307,6 +308,15 @@ void index_stats(vdb_index_s *h, hipStream_t st) {
     }
 }
 
+// row-major int8 copy of h->x32 (byte-valued corpora only) for the list refine
+void build_rows_i8(vdb_index_s *h, hipStream_t st) {
+    h->rows8_pitch = (h->dim + 15) / 16 * 16;
+    h->rows8.reserve((size_t)h->N * h->rows8_pitch);
+    const int64_t words = h->N * (h->rows8_pitch / 4);
+    build_rows_i8_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(
+        h->x32.as<float>(), h->N, h->dim, h->D4, h->rows8_pitch, h->i8_cx, h->rows8.as<signed char>());
+}
+
 void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base,
                  hipStream_t st) {
     if (n < 0) throw Error(VDB_ERR_INVALID, "negative row count");
@@ -362,6 +372,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
             h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
             build_bias_i8_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(
                 h->x32.as<float>(), n, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>());
+            build_rows_i8(h, st);
             VDB_HIP(hipGetLastError());
             VDB_HIP(hipStreamSynchronize(st));
         }
@@ -585,6 +596,12 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         qpad = ws.qpad.as<float>();
     }
     RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k, nullptr};
+    if (h->i8_ok && h->rows8.p && !h->i8_disable) {       // (used only by batches the device puts on the int8 scan)
+        rc.X8 = h->rows8.as<signed char>();
+        rc.x8_pitch = h->rows8_pitch;
+        rc.cx = h->i8_cx;
+        rc.info = batch_info(ws);
+    }
 
     ScanGeom g;
     const bool exact_only = h->force_path == 1 || h->force_path == 3;   // 3: also without query blocking (A/B runs)
@@ -667,7 +684,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             const int kpl = kpl_for(k);
             if (h->Npad <= 2048 && kpl <= 4) {       // scores in registers, 4 queries per workgroup (dense.hpp)
                 const dim3 g4((unsigned)((nq + 3) / 4));
-                const size_t lds4 = (size_t)4 * cand_cap * 4;
+                const size_t lds4 = (size_t)4 * 2 * cand_cap * 4;       // per wave: candidate rows + their keys
                 if (h->Npad <= 1024) {
                     DISPATCH_KPL(kpl, (dense_select_reg_kernel<(KPL <= 4 ? KPL : 4), 16><<<g4, dim3(256), lds4, st>>>(da)));
                 } else {
@@ -1103,7 +1120,7 @@ int vdb_destroy(vdb_handle h) {
         if (!h) return;
         set_device(h->device);
         (void)hipDeviceSynchronize();
-        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->ivf_offsets, &h->ivf_ids,
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
                          &h->ivf_cnt, &h->ivf_cursor, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_query, &h->ivf_slot_of};
@@ -1309,7 +1326,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.metric = h->metric;
         s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
         s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
-                                     h->panels8.cap + h->bias8.cap + h->ws.bytes());
+                                     h->panels8.cap + h->bias8.cap + h->rows8.cap + h->ws.bytes());
         s.has_i8_copy = h->i8_ok ? 1 : 0;
         s.upload_blocks = h->last_upload_blocks;
         s.last_rows_scanned = 0;
