@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -o $name -- \
-      python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1 || echo "pass $name failed"
+      python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 BENCH_ARGS=("$@")
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA

@@ -511,6 +511,13 @@ def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metr
     np.testing.assert_array_equal(I1, I)
     np.testing.assert_array_equal(D1, D)
     idx.set_option("panel_dtype", 0)
+    # select on quads (4 rows per candidate) instead of the default octs: same result
+    idx.set_option("i8_group", 4)
+    D4, I4 = idx.search(Q, k)
+    assert idx.stats()["scan_dtype"] == 1
+    np.testing.assert_array_equal(I4, I)
+    np.testing.assert_array_equal(D4, D)
+    idx.set_option("i8_group", 8)
     # a batch with one non-integer value, or one value outside the byte window, is served by the fp16 scan
     for bad in (0.5, 300.0):
         Q2 = Q.copy()

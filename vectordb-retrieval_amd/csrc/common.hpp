@@ -66,7 +66,8 @@ struct QueryBatchInfo {   // per search call, device resident
     float bscale;         // factor applied to the B operand (-2*sq for L2, -sq for IP)
     int force_fallback;   // scales unusable (non-finite input / overflow): every query takes the exhaustive path
     int not_u8, not_s8;   // query values outside the integers 0..255 / -128..127
-    int i8_mode;          // 0: fp16 scan.  1 / 2: int8 scan (scan_i8.hpp), queries in the u8 / s8 window
+    int i8_mode;          // 0: fp16 scan.  Else int8 scan (scan_i8.hpp): bits 0-1 = query window (1 u8, 2 s8), bit 2 = the
+                          // select works on groups of 8 rows (octs) instead of 4 (quads)
     unsigned done_blocks; // workgroups of query_stats_kernel that have contributed (the last one finalises the scales)
 };
 static_assert(sizeof(QueryBatchInfo) + 16 <= 64, "QueryBatchInfo must fit the first 64 bytes of ws.small");
@@ -82,6 +83,14 @@ static_assert(sizeof(QueryBatchInfo) + 16 <= 64, "QueryBatchInfo must fit the fi
 // The offset makes every t' positive, the select packs v = (t' << 6) | quad id, and v read as a float bit pattern
 // is a normal positive float whose order is the integer order -- the bin arrays and the select kernels are shared
 // with the fp16 path (only T^ = tau + 2 eps is formed in integer arithmetic).
+// A packed key names a GROUP of consecutive rows inside its bin: low 6 bits = group id, first row = id * group rows.
+// fp16 scan: quads (4 rows).  int8 scan: octs (8 rows) by default -- the integer select is VALU-issue bound beside the
+// double-rate MFMAs and an oct costs 7 ops per 8 scores against 5 per 4, while its exact re-scoring reads the 128-byte
+// int8 rows (refine.hpp, X8), so twice the candidate rows still gather half the bytes of quads of float32 rows.
+__host__ __device__ inline int group_rows_of(int i8_mode) { return (i8_mode & 4) ? 8 : 4; }
+__host__ __device__ inline int cand_row_offset(unsigned packed_bits, int i8_mode) {
+    return (int)(packed_bits & 0x3Fu) * group_rows_of(i8_mode);
+}
 constexpr int kI8Offset = 1 << 24;
 constexpr int kI8PadBias = 30000000;          // accumulator init of padding rows: above every real t', (t' << 6) < +inf bits
 constexpr unsigned kI8Inf = 0x7f800000u;      // "+inf" of the packed integer keys (bits of float +inf)

@@ -145,7 +145,8 @@ struct FinalizeArgs {
     int metric;
     int corpus_int_unscaled;
     float maxnorm2;
-    int corpus_i8;             // the index holds an int8 scan copy and this search may use it (0 = fp16 scan only)
+    int corpus_i8;             // 0 = fp16 scan only; else the index holds an int8 scan copy this search may use: 1 = select on
+                               // quads, 5 = on octs (bit 2 is copied into QueryBatchInfo.i8_mode)
 };
 __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &f) {
     const float amax = __uint_as_float(__hip_atomic_load(&info->absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -167,7 +168,10 @@ __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &
     const float top = sq * f.sx * f.maxnorm2;
     info->force_fallback = (nonfinite || !(top < 1.0e30f) || !(sq * f.sx > 1.0e-30f)) ? 1 : 0;
     info->i8_mode = 0;
-    if (f.corpus_i8 && !nonfinite) info->i8_mode = !not_u8 ? 1 : (!not_s8 ? 2 : 0);
+    if (f.corpus_i8 && !nonfinite) {
+        const int window = !not_u8 ? 1 : (!not_s8 ? 2 : 0);
+        info->i8_mode = window ? (window | (f.corpus_i8 & 4)) : 0;
+    }
 }
 
 // Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics + fence per workgroup

@@ -202,10 +202,11 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
     nres = nres < a.rescan_cap ? nres : a.rescan_cap;
     const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
     const bool use8 = a.c.X8 != nullptr && a.c.info != nullptr && a.c.info->i8_mode != 0;   // int8 rows, integer arithmetic
-    for (int base = 0; base < ncand * 4; base += 64) {       // a candidate is a quad of 4 consecutive rows
+    const int gshift = (a.c.info != nullptr && (a.c.info->i8_mode & 4)) ? 3 : 2;      // candidate = 4 or 8 consecutive rows
+    for (int base = 0; base < (ncand << gshift); base += 64) {
         const int i = base + lane;
-        bool valid = i < ncand * 4;
-        int64_t row = valid ? (int64_t)cr[i >> 2] + (i & 3) : 0;
+        bool valid = i < (ncand << gshift);
+        int64_t row = valid ? (int64_t)cr[i >> gshift] + (i & ((1 << gshift) - 1)) : 0;
         valid = valid && row < a.c.N;
         uint64_t key = ~0ull;
         if (valid) key = row_key(a.c, row, qptr, use8);

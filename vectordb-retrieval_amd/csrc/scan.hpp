@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                 const unsigned long long smask = __ballot(single), rmask = __ballot(deep);
                 if (single) {
                     const int pos = ncand + __popcll(smask & lt_mask);
-                    if (pos < a.cand_cap) cr[pos] = row0 + quad_row_offset(__float_as_uint(m1));
+                    if (pos < a.cand_cap) cr[pos] = row0 + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
                 }
                 if (deep) {
                     const int pos = nres + __popcll(rmask & lt_mask);
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             if (single) {
                 const int pos = ncand + __popcll(smask & lt_mask);
                 const int hh = s % a.groups;
-                const int row = (sspan * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(m1));
+                const int row = (sspan * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
                 if (pos < a.cand_cap) cr[pos] = row;
             }
             ncand += __popcll(smask);
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if (cand) {
                         const int pos = ncand + __popcll(cm & lt_mask);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
+                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), a.info->i8_mode));
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
-                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(m1));
+                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
             } else {               // two or more interesting scores: queue the superbin for the cooperative walk below
                 const int pos = atomicAdd(cnt_d, 1);
                 if (pos < kDeepCap) deep[pos] = s;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                 } else {
                     const int pos = atomicAdd(cnt_c, 1);
                     if (pos < a.cand_cap)
-                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + quad_row_offset(__float_as_uint(bm1)));
+                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), a.info->i8_mode));
                 }
             }
         }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__re
     const int64_t qt = tk / ks32;
     const int mode = info->i8_mode;
     if (qt >= nqtiles || !mode) return;
-    const int cq = mode == 1 ? 127 : -1;
+    const int cq = (mode & 3) == 1 ? 127 : -1;
     const int64_t q = qt * 32 + (lane & 31);
     const int d0 = ks * 32 + (lane >> 5) * 16;
     int4v out;
@@ -149,16 +149,21 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }   // v_med3_i32
 
-// select of one tile: per column block 4 quads of 4 consecutive corpus rows; v = (min of the quad << 6) | quad id
-template <int CB, bool M3 = false>
+// select of one tile: per column block 16/G groups of G consecutive corpus rows (G = 4 quads, 8 octs);
+// v = (min of the group << 6) | group id.  The id is forced into an SGPR: in the rolled tile loop hipcc otherwise packs
+// with a shift and a three-operand add (2 VALU ops) instead of one v_lshl_or_b32.
+template <int CB, bool M3 = false, int G = 4>
 __device__ __forceinline__ void select_phase_i8(const int16v (&acc)[CB], int (&m1)[CB], int (&m2)[CB], unsigned id0,
                                                 int *m3 = nullptr) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 16 / G; ++g) {
+        const unsigned idg = (unsigned)__builtin_amdgcn_readfirstlane((int)(id0 + g));
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int q = imin(imin(acc[cb][4 * g], acc[cb][4 * g + 1]), imin(acc[cb][4 * g + 2], acc[cb][4 * g + 3]));
-            const int v = (int)(((unsigned)q << 6) | (id0 + g));
+            int q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
+            if (G == 8)
+                q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+            const int v = (int)(((unsigned)q << 6) | idg);
             if (M3) m3[cb] = imed3(m2[cb], m3[cb], v);       // (items mode: third minimum, see scan.hpp select_phase)
             m2[cb] = imed3(m1[cb], m2[cb], v);
             m1[cb] = imin(m1[cb], v);
@@ -192,9 +197,11 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // 64 queries per wave as scan_kernel, 4 -> 128: every A fragment read from LDS feeds 4 MFMAs and a stage carries twice
 // the matrix work per barrier).  NWAVES waves, 2 per SIMD, phase-staggered halves exactly as scan_kernel: the early half
 // runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).  BT: tiles per level-1 bin; ITEMS: IVF work-item
-// mode (one inverted list x one group of query slots, bins laid out [item][slot][bin], third minimum kept).
-template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false>
-__global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
+// mode (one inverted list x one group of query slots, bins laid out [item][slot][bin], third minimum kept); G: rows per
+// select group (must match bit 2 of QueryBatchInfo.i8_mode, which the select and refine kernels read).
+template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8>
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : 2)) void scan_i8_kernel(ScanI8Args a) {
+    constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
         out_pitch = a.Qpad;
         out_col = q0 + (lane & 31);
     }
-    const int32_t *bias = a.bias8 + (mode == 1 ? 0 : a.Npad);
+    const int32_t *bias = a.bias8 + ((mode & 3) == 1 ? 0 : a.Npad);
 
     int4v bq[CB][KS];
     if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) << 2), m3);
+                select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) * GPT), m3);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase_i8<KS>(A + t * KS * 64, B4 + t * 8, fr, cin, lane);
                 const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
-                select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)((tp % BT) << 2), m3);
+                select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((tp % BT) * GPT), m3);
                 if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_i8_kernel(ScanI8Args a) {
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
             __syncthreads();
         }
-        select_phase_i8<CB, ITEMS>(acc, m1, m2, (unsigned)((BT - 1) << 2), m3);
+        select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((BT - 1) * GPT), m3);
         flush_bin(span1 - 1, BPS - 1);
     }
     if (ITEMS) return;
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(256) void ivf_qrows_i8_kernel(const float *__restri
     if (i >= nq * Dpad || !mode) return;
     const int64_t q = i / Dpad;
     const int d = (int)(i - q * Dpad);
-    const int cq = mode == 1 ? 127 : -1;
+    const int cq = (mode & 3) == 1 ? 127 : -1;
     qrows[i] = (signed char)(d < D ? cq - (int)Q[(size_t)q * D + d] : 0);
 }
 

@@ -99,6 +99,7 @@ struct vdb_index_s {
     DevBuf panels8, bias8, rows8;            // rows8: row-major int8 copy for the list refine (refine.hpp, X8)
     int rows8_pitch = 0;
     bool i8_ok = false;
+    int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
@@ -596,11 +597,11 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         qpad = ws.qpad.as<float>();
     }
     RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k, nullptr};
+    rc.info = batch_info(ws);                             // (group size of the candidates: 4 rows, 8 on the int8 scan)
     if (h->i8_ok && h->rows8.p && !h->i8_disable) {       // (used only by batches the device puts on the int8 scan)
         rc.X8 = h->rows8.as<signed char>();
         rc.x8_pitch = h->rows8_pitch;
         rc.cx = h->i8_cx;
-        rc.info = batch_info(ws);
     }
 
     ScanGeom g;
@@ -824,7 +825,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     {
         const int64_t total = nq * Dm;
         query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
-            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, use_i8 ? 1 : 0});
+            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2,
+                         use_i8 ? (1 | (h->i8_group == 8 ? 4 : 0)) : 0});
         if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
             ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
             const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;
@@ -882,16 +884,25 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
 #ifdef VDB_ABLATIONS
         s8.abl_no_bins = (h->i8_variant & 4) ? 1 : 0;
 #endif
-        const int v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 3) : (h->i8_variant & 1);
-        const int qtile = (v8 & 2) ? 1024 : 512;
+        int v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 7) : (h->i8_variant & 1);
+#ifdef VDB_ABLATIONS
+        v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 3) : (h->i8_variant & 1);
+#endif
+        if (v8 > 5) v8 = 3;
+        const int qtile = (v8 >= 2) ? 1024 : 512;
         s8.nqtiles = (int)(Qpad / qtile);
         const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
-#define VDB_I8(KS_, ST_, CB_) scan_i8_kernel<KS_, ST_, CB_><<<grid8, dim3(512), 0, st>>>(s8)
+#define VDB_I8G(KS_, ST_, CB_, NW_, G_) scan_i8_kernel<KS_, ST_, CB_, NW_, 16, false, G_><<<grid8, dim3(NW_ * 64), 0, st>>>(s8)
+#define VDB_I8(KS_, ST_, CB_, NW_) do { if (h->i8_group == 8) VDB_I8G(KS_, ST_, CB_, NW_, 8); else VDB_I8G(KS_, ST_, CB_, NW_, 4); } while (0)
+        // variants 4, 5: 16 / 12... 16 waves per workgroup = 4 per SIMD, 64 queries each (1024-query tiles), rolled tile loop
         if (h->i8_ks == 2) {
-            switch (v8) { case 1: VDB_I8(2, 8, 2); break; case 2: VDB_I8(2, 4, 4); break; case 3: VDB_I8(2, 8, 4); break; default: VDB_I8(2, 4, 2); }
+            switch (v8) { case 1: VDB_I8(2, 8, 2, 8); break; case 2: VDB_I8(2, 4, 4, 8); break; case 3: VDB_I8(2, 8, 4, 8); break;
+                          case 4: VDB_I8(2, 8, 2, 16); break; case 5: VDB_I8(2, 16, 2, 16); break; default: VDB_I8(2, 4, 2, 8); }
         } else {
-            switch (v8) { case 1: VDB_I8(4, 8, 2); break; case 2: VDB_I8(4, 4, 4); break; case 3: VDB_I8(4, 8, 4); break; default: VDB_I8(4, 4, 2); }
+            switch (v8) { case 1: VDB_I8(4, 8, 2, 8); break; case 2: VDB_I8(4, 4, 4, 8); break; case 3: VDB_I8(4, 8, 4, 8); break;
+                          case 4: VDB_I8(4, 8, 2, 16); break; case 5: VDB_I8(4, 16, 2, 16); break; default: VDB_I8(4, 4, 2, 8); }
         }
+#undef VDB_I8G
 #undef VDB_I8
         VDB_HIP(hipGetLastError());
     }
@@ -1419,11 +1430,14 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "upload_block_mb") {   // staging block of the row-block ingestion (0 = default 64 MiB)
             if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "upload_block_mb out of range");
             h->upload_block_mb = (int)value;
+        } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
+            if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
+            h->i8_group = (int)value;
         } else if (k == "i8_variant") {
 #ifdef VDB_ABLATIONS
             if (value < 0 || value > 7) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..7");     // +4: no bin stores (timing only)
 #else
-            if (value < 0 || value > 3) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..3");
+            if (value < 0 || value > 5) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5");
 #endif
             h->i8_variant = (int)value;
         } else if (k == "kloop_qgroup") {
