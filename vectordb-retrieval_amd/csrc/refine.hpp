@@ -19,46 +19,19 @@ struct RefineCommon {
     int metric;
     int k;
     const int64_t *idmap;  // optional: id of row r is idmap[r] (IVF: rows are grouped by list), else id_base + r
-    // byte-valued corpora (scan_i8.hpp): row-major int8 copy x - cx, x8_pitch bytes per row (padding bytes hold -cx, i.e.
-    // x = 0).  When the batch is integer too (info->i8_mode) the list refine scores from it in exact integer arithmetic:
-    // the sums are the same integers the float64 chain produces, so the keys are bit-identical, at a quarter of the
-    // gathered bytes (the refine is bound by the gather of 512-byte float32 rows).
+    // byte-valued corpora (scan_i8.hpp): row-major int8 copy x - cx, x8_pitch = 64 or 128 bytes per row (padding bytes
+    // hold -cx, i.e. x = 0), rowstat[row] = {sum x^2, sum x}, and Q8 = the batch's int8 query rows cq - q (padding 0).
+    // When the batch is integer too (info->i8_mode) the list refine scores from them in exact integer arithmetic with
+    // v_dot4c_i32_i8 (query row in SGPRs): the results are the same integers the float64 chain produces, so the keys are
+    // bit-identical, from 136 gathered bytes per row instead of 512 (the refine is bound by that gather).
     const signed char *X8 = nullptr;
-    int x8_pitch = 0, cx = 0;
+    const int *rowstat = nullptr;
+    const signed char *Q8 = nullptr;
+    int x8_pitch = 0, cx = 0, D = 0;
     const QueryBatchInfo *info = nullptr;
 };
 
 typedef int refine_int4 __attribute__((ext_vector_type(4)));
-
-// exact key of one row from the int8 copy; q holds integers (checked by the batch statistics)
-__device__ __forceinline__ uint64_t exact_key_i8(const signed char *__restrict__ x, const float *__restrict__ q, int D4,
-                                                 int cx, int metric) {
-    int acc = 0;       // |x - q| <= 383, D <= 128: the sums stay below 2^25
-    const int n16 = D4 / 16;
-    const refine_int4 *xv = reinterpret_cast<const refine_int4 *>(x);
-    const float4 *qv = reinterpret_cast<const float4 *>(q);
-    auto word = [&](int w, const float4 &b) {
-        const int x0 = (int)(signed char)(w & 0xff) + cx, x1 = (int)(signed char)((w >> 8) & 0xff) + cx;
-        const int x2 = (int)(signed char)((w >> 16) & 0xff) + cx, x3 = (w >> 24) + cx;
-        const int q0 = (int)b.x, q1 = (int)b.y, q2 = (int)b.z, q3 = (int)b.w;
-        if (metric == 0) {
-            const int t0 = x0 - q0, t1 = x1 - q1, t2 = x2 - q2, t3 = x3 - q3;
-            acc += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-        } else {
-            acc += x0 * q0 + x1 * q1 + x2 * q2 + x3 * q3;
-        }
-    };
-#pragma unroll 8
-    for (int i = 0; i < n16; ++i) {
-        const refine_int4 w = xv[i];
-        word(w.x, qv[4 * i]); word(w.y, qv[4 * i + 1]); word(w.z, qv[4 * i + 2]); word(w.w, qv[4 * i + 3]);
-    }
-    const int *xw = reinterpret_cast<const int *>(x);
-    for (int i = n16 * 4; i < D4 / 4; ++i) word(xw[i], qv[i]);
-    return sortable_u64(metric == 0 ? (double)acc : -(double)acc);
-}
-
-
 
 __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const float *__restrict__ q, int D4,
                                               int metric) {
@@ -89,12 +62,6 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
         }
         return sortable_u64(-acc);
     }
-}
-
-// key of row `row` in whichever copy the batch may use (use8: wave-uniform)
-__device__ __forceinline__ uint64_t row_key(const RefineCommon &c, int64_t row, const float *qptr, bool use8) {
-    return use8 ? exact_key_i8(c.X8 + (size_t)row * c.x8_pitch, qptr, c.D4, c.cx, c.metric)
-                : exact_key(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
 }
 
 // QB keys of ONE row against QB queries: the row is fetched once; every query keeps its own sequential chain, so each
@@ -132,14 +99,14 @@ __device__ __forceinline__ void exact_keys(const float *__restrict__ x, const fl
 
 template <int KPL>
 __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon &c, const float *qptr, int64_t row0,
-                                          int64_t row1, bool use8 = false) {
+                                          int64_t row1) {
     const int lane = threadIdx.x & 63;
     if (row1 > c.N) row1 = c.N;
     for (int64_t base = row0; base < row1; base += 64) {
         const int64_t row = base + lane;
         const bool valid = row < row1;
         uint64_t key = ~0ull;
-        if (valid) key = row_key(c, row, qptr, use8);
+        if (valid) key = exact_key(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
         tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
     }
 }
@@ -187,6 +154,73 @@ struct RefineListArgs {
     int64_t *pids;
 };
 
+// int8 form of the list refine for one query (wave): W = x8_pitch / 4 dwords per row.  The query's int8 row b = cq - q
+// sits in SGPRs; per row  dot = sum (x - cx)(cq - q)  by W v_dot4c, and with n2 = sum x^2, s1 = sum x of the row
+//   x.q     = -dot + cq s1 + cx sum(q) - D cx cq          ||x - q||^2 = n2 - 2 x.q + sum(q^2)
+// -- all exact integers below 2^27, equal to what the canonical float64 chain computes on these integer inputs.
+template <int KPL, int W>
+__device__ __forceinline__ void refine_list_dot8(const RefineListArgs &a, int64_t q, int ncand, int nres, int gshift,
+                                                 WaveTopK<KPL> &tk) {
+    const int lane = threadIdx.x & 63;
+    const RefineCommon &c = a.c;
+    const int mode = c.info->i8_mode;
+    const int cq = (mode & 3) == 1 ? 127 : -1;
+    int qb[W];
+    const int *q8 = reinterpret_cast<const int *>(c.Q8 + (size_t)q * c.x8_pitch);      // wave-uniform: scalar loads
+#pragma unroll
+    for (int w = 0; w < W; ++w) qb[w] = __builtin_amdgcn_readfirstlane(q8[w]);
+    // per query: sum q, sum q^2 (q holds integers)
+    int sq = 0, sqq = 0;
+    const float *qf = c.Q + (size_t)q * c.D4;
+    for (int d = lane; d < c.D4; d += 64) {
+        const int v = (int)qf[d];
+        sq += v;
+        sqq += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sq += __shfl_xor(sq, o);
+        sqq += __shfl_xor(sqq, o);
+    }
+    const long long cxq = (long long)c.cx * sq - (long long)c.D * c.cx * cq;          // cx sum(q) - D cx cq
+    auto key_of = [&](int64_t row) -> uint64_t {
+        const refine_int4 *xr = reinterpret_cast<const refine_int4 *>(c.X8 + (size_t)row * c.x8_pitch);
+        const int2 st = reinterpret_cast<const int2 *>(c.rowstat)[row];
+        int dot = 0;
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) {
+            const refine_int4 w = xr[i];
+            dot = __builtin_amdgcn_sdot4(w.x, qb[4 * i], dot, false);
+            dot = __builtin_amdgcn_sdot4(w.y, qb[4 * i + 1], dot, false);
+            dot = __builtin_amdgcn_sdot4(w.z, qb[4 * i + 2], dot, false);
+            dot = __builtin_amdgcn_sdot4(w.w, qb[4 * i + 3], dot, false);
+        }
+        const long long xq = -(long long)dot + (long long)cq * st.y + cxq;
+        return c.metric == 0 ? sortable_u64((double)((long long)st.x - 2 * xq + sqq)) : sortable_u64(-(double)xq);
+    };
+    const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
+    for (int base = 0; base < (ncand << gshift); base += 64) {
+        const int i = base + lane;
+        bool valid = i < (ncand << gshift);
+        const int64_t row = valid ? (int64_t)cr[i >> gshift] + (i & ((1 << gshift) - 1)) : 0;
+        valid = valid && row < c.N;
+        const uint64_t key = valid ? key_of(row) : ~0ull;
+        tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
+    }
+    const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+    for (int r = 0; r < nres; ++r) {
+        const int64_t row0 = rr[2 * r];
+        int64_t row1 = rr[2 * r + 1];
+        if (row1 > c.N) row1 = c.N;
+        for (int64_t base = row0; base < row1; base += 64) {
+            const int64_t row = base + lane;
+            const bool valid = row < row1;
+            const uint64_t key = valid ? key_of(row) : ~0ull;
+            tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
+        }
+    }
+}
+
 template <int KPL>
 __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
     const int lane = threadIdx.x & 63;
@@ -201,19 +235,24 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
     ncand = ncand < a.cand_cap ? ncand : a.cand_cap;
     nres = nres < a.rescan_cap ? nres : a.rescan_cap;
     const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
-    const bool use8 = a.c.X8 != nullptr && a.c.info != nullptr && a.c.info->i8_mode != 0;   // int8 rows, integer arithmetic
-    const int gshift = (a.c.info != nullptr && (a.c.info->i8_mode & 4)) ? 3 : 2;      // candidate = 4 or 8 consecutive rows
-    for (int base = 0; base < (ncand << gshift); base += 64) {
-        const int i = base + lane;
-        bool valid = i < (ncand << gshift);
-        int64_t row = valid ? (int64_t)cr[i >> gshift] + (i & ((1 << gshift) - 1)) : 0;
-        valid = valid && row < a.c.N;
-        uint64_t key = ~0ull;
-        if (valid) key = row_key(a.c, row, qptr, use8);
-        tk.offer(key, a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row, valid);
+    const int mode = a.c.info != nullptr ? a.c.info->i8_mode : 0;
+    const int gshift = (mode & 4) ? 3 : 2;                       // a candidate = 4 or 8 consecutive rows
+    if (mode != 0 && a.c.X8 != nullptr) {                        // integer batch on a byte-valued corpus: int8 rows
+        if (a.c.x8_pitch == 64) refine_list_dot8<KPL, 16>(a, q, ncand, nres, gshift, tk);
+        else refine_list_dot8<KPL, 32>(a, q, ncand, nres, gshift, tk);
+    } else {
+        for (int base = 0; base < (ncand << gshift); base += 64) {
+            const int i = base + lane;
+            bool valid = i < (ncand << gshift);
+            int64_t row = valid ? (int64_t)cr[i >> gshift] + (i & ((1 << gshift) - 1)) : 0;
+            valid = valid && row < a.c.N;
+            uint64_t key = ~0ull;
+            if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+            tk.offer(key, a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row, valid);
+        }
+        const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+        for (int r = 0; r < nres; ++r) scan_rows<KPL>(tk, a.c, qptr, rr[2 * r], rr[2 * r + 1]);
     }
-    const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
-    for (int r = 0; r < nres; ++r) scan_rows<KPL>(tk, a.c, qptr, rr[2 * r], rr[2 * r + 1], use8);
     const size_t o = (size_t)q * a.c.k;
     write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
                     a.pids ? a.pids + o : nullptr);

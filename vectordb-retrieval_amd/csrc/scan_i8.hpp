@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__res
 
 // accumulator init per row, for both query windows: bias8[w][row], w = 0 (cq = 127), 1 (cq = -1)
 //   L2: floor((||x||^2 - 2 cq sum(x)) / 2) + kI8Offset     IP: -cq sum(x) + kI8Offset     padding rows: kI8PadBias
+// (also rowstat[row] = {sum x^2, sum x} for the int8 list refine, refine.hpp)
 __global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restrict__ X, int64_t N, int64_t Npad, int D,
-                                                            int D4, int metric, int32_t *__restrict__ bias8) {
+                                                            int D4, int metric, int32_t *__restrict__ bias8,
+                                                            int *__restrict__ rowstat) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= Npad) return;
     if (row >= N) {
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restr
         n2 += v * v;
         s1 += v;
     }
+    rowstat[2 * row] = (int)n2;
+    rowstat[2 * row + 1] = (int)s1;
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
         const long long cq = w == 0 ? 127 : -1;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void ivf_build_panels_i8_kernel(const float *_
 __global__ __launch_bounds__(256) void ivf_build_bias_i8_kernel(const float *__restrict__ X, int64_t nspans, int D, int D4,
                                                                 int metric, const int32_t *__restrict__ span_row0,
                                                                 const int32_t *__restrict__ span_valid,
-                                                                int32_t *__restrict__ bias8) {
+                                                                int32_t *__restrict__ bias8, int *__restrict__ rowstat) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = nspans * kSpanRows;
     if (i >= total) return;
@@ -472,6 +476,8 @@ __global__ __launch_bounds__(256) void ivf_build_bias_i8_kernel(const float *__r
         n2 += v * v;
         s1 += v;
     }
+    rowstat[2 * row] = (int)n2;
+    rowstat[2 * row + 1] = (int)s1;
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
         const long long cq = w == 0 ? 127 : -1;

@@ -60,13 +60,13 @@ struct Workspace;
 inline QueryBatchInfo *batch_info(Workspace &ws);
 
 struct Workspace {
-    DevBuf qpad, qpanels, qpanels8, info, eps, bin_m1, bin_m2, bin_m3, sb_m1, sb_m2, sb_span;
+    DevBuf qpad, qpanels, qpanels8, qrows8, info, eps, bin_m1, bin_m2, bin_m3, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
-        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
+        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
                                &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
                                &stage_i, &dense};
         size_t s = 0;
@@ -74,7 +74,7 @@ struct Workspace {
         return s;
     }
     void release() {
-        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
+        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
                          &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
                          &dense};
         for (auto b : all) b->release();
@@ -96,7 +96,7 @@ struct vdb_index_s {
     DevBuf x32, xnorm2, panels, bias, stats;
     // int8 scan copy (scan_i8.hpp): byte-valued integer corpora with D <= 128, kept NEXT TO the fp16 panels (a batch of
     // non-integer queries still takes the fp16 scan)
-    DevBuf panels8, bias8, rows8;            // rows8: row-major int8 copy for the list refine (refine.hpp, X8)
+    DevBuf panels8, bias8, rows8, rowstat8;  // rows8 / rowstat8: row-major int8 copy + {sum x^2, sum x} for the list refine
     int rows8_pitch = 0;
     bool i8_ok = false;
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
@@ -311,7 +311,7 @@ void index_stats(vdb_index_s *h, hipStream_t st) {
 
 // row-major int8 copy of h->x32 (byte-valued corpora only) for the list refine
 void build_rows_i8(vdb_index_s *h, hipStream_t st) {
-    h->rows8_pitch = (h->dim + 15) / 16 * 16;
+    h->rows8_pitch = h->i8_ks * 32;                        // = the pitch of the int8 query rows (64 or 128 bytes)
     h->rows8.reserve((size_t)h->N * h->rows8_pitch);
     const int64_t words = h->N * (h->rows8_pitch / 4);
     build_rows_i8_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(
@@ -371,8 +371,9 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
             build_panels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
                 h->x32.as<float>(), n, D, D4, h->i8_ks, ntiles, h->i8_cx, h->panels8.as<int4v>());
             h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
+            h->rowstat8.reserve((size_t)n * 2 * sizeof(int));
             build_bias_i8_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(
-                h->x32.as<float>(), n, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>());
+                h->x32.as<float>(), n, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>(), h->rowstat8.as<int>());
             build_rows_i8(h, st);
             VDB_HIP(hipGetLastError());
             VDB_HIP(hipStreamSynchronize(st));
@@ -600,8 +601,12 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     rc.info = batch_info(ws);                             // (group size of the candidates: 4 rows, 8 on the int8 scan)
     if (h->i8_ok && h->rows8.p && !h->i8_disable) {       // (used only by batches the device puts on the int8 scan)
         rc.X8 = h->rows8.as<signed char>();
+        rc.rowstat = h->rowstat8.as<int>();
         rc.x8_pitch = h->rows8_pitch;
         rc.cx = h->i8_cx;
+        rc.D = Dm;
+        ws.qrows8.reserve((size_t)nq * h->rows8_pitch);
+        rc.Q8 = ws.qrows8.as<signed char>();               // (filled next to the B fragments when the int8 scan is offered)
     }
 
     ScanGeom g;
@@ -832,6 +837,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;
             build_qpanels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
                 dq, nq, Dm, h->i8_ks, Qpad / 32, info, ws.qpanels8.as<int4v>());
+            if (rc.Q8)      // row-major int8 query rows for the list refine (refine.hpp)
+                ivf_qrows_i8_kernel<<<dim3((unsigned)((nq * h->rows8_pitch + 255) / 256)), dim3(256), 0, st>>>(
+                    dq, nq, Dm, h->rows8_pitch, info, ws.qrows8.as<signed char>());
         }
         const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
         if (h->tile16)
@@ -1131,7 +1139,7 @@ int vdb_destroy(vdb_handle h) {
         if (!h) return;
         set_device(h->device);
         (void)hipDeviceSynchronize();
-        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->ivf_offsets, &h->ivf_ids,
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
                          &h->ivf_cnt, &h->ivf_cursor, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_query, &h->ivf_slot_of};
@@ -1337,7 +1345,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.metric = h->metric;
         s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
         s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
-                                     h->panels8.cap + h->bias8.cap + h->rows8.cap + h->ws.bytes());
+                                     h->panels8.cap + h->bias8.cap + h->rows8.cap + h->rowstat8.cap + h->ws.bytes());
         s.has_i8_copy = h->i8_ok ? 1 : 0;
         s.upload_blocks = h->last_upload_blocks;
         s.last_rows_scanned = 0;
