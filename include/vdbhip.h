@@ -139,6 +139,10 @@ int vdb_ivf_set_centroids(vdb_handle h, const float *centroids_host, int nlist);
 int vdb_ivf_get_centroids(vdb_handle h, float *centroids_host);
 /* assign rows to their nearest centroid and build the inverted lists (CSR, vectors grouped by list) */
 int vdb_ivf_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
+/* same with the list of every row given (int32 (n), as vdb_ivf_get_assignment returned it for this corpus and these
+ * centroids): what loading a persisted index does -- no coarse assignment pass (covertree_v2_2.py:184-282 is the
+ * reference's load protocol).  A row whose list id is out of range is an error. */
+int vdb_ivf_add_assigned(vdb_handle h, const float *x_host, int64_t n, int64_t id_base, const int32_t *list_of_row_host);
 int vdb_ivf_set_nprobe(vdb_handle h, int nprobe);
 /* list id of each indexed row, int32 (n) -- parity tests compare it with the oracle's assignment */
 int vdb_ivf_get_assignment(vdb_handle h, int32_t *list_of_row_host);

@@ -233,15 +233,22 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restr
     }
 }
 
-// scaled fp16 copy of the query rows, [nq][16*ksteps]; the scan kernel gathers its B fragments from it
+// query rows the list scan gathers its B fragments from, [nq][Dpad]: scaled fp16 (fp16 scan) or, when the batch is on
+// the int8 scan (info->i8_mode) and q8 is given, int8 cq - q -- one kernel, whichever the device chose
 __global__ __launch_bounds__(256) void ivf_qrows_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
                                                         const QueryBatchInfo *__restrict__ info,
-                                                        _Float16 *__restrict__ qrows) {
+                                                        _Float16 *__restrict__ qrows, signed char *__restrict__ q8) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * Dpad || info->i8_mode) return;
+    if (i >= nq * Dpad) return;
     const int64_t q = i / Dpad;
     const int d = (int)(i - q * Dpad);
-    qrows[i] = (_Float16)(d < D ? Q[(size_t)q * D + d] * info->bscale : 0.f);
+    const int mode = info->i8_mode;
+    if (mode && q8) {
+        const int cq = (mode & 3) == 1 ? 127 : -1;
+        q8[i] = (signed char)(d < D ? cq - (int)Q[(size_t)q * D + d] : 0);
+    } else {
+        qrows[i] = (_Float16)(d < D ? Q[(size_t)q * D + d] * info->bscale : 0.f);
+    }
 }
 
 // ---- select over the bins of a query's probed lists ----------------------------------------------------

@@ -174,6 +174,18 @@ __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &
     }
 }
 
+// One thread: scales of a batch whose statistics were already taken by another index on the SAME queries (the coarse
+// quantizer of an IVF index scans the batch first): copy the five statistics, finalise with this index's scales.
+__global__ void query_finalize_from_kernel(QueryBatchInfo *info, const QueryBatchInfo *src, FinalizeArgs fin) {
+    info->absmax_bits = src->absmax_bits;
+    info->not_integer = src->not_integer;
+    info->nonfinite = src->nonfinite;
+    info->not_u8 = src->not_u8;
+    info->not_s8 = src->not_s8;
+    __threadfence_block();
+    query_finalize(info, fin);
+}
+
 // Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics + fence per workgroup
 // (same addresses for everybody) stays a few dozen operations -- 1250 workgroups cost 21 us on a 5 MB batch, the
 // read itself takes 1-2.

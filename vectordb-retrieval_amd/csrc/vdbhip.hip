@@ -113,6 +113,7 @@ struct vdb_index_s {
     // options
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
+    int64_t info_valid_nq = -1;              // queries whose statistics the last search_batch left in batch_info(ws) (-1: none)
     bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
     bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
                                              // not their order or distances (dense.hpp, DenseSelectArgs.set_only)
@@ -625,6 +626,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
                (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
     // (corpora of 8193..15360 rows whose chunking cannot give 4k superbins still have the dense path below)
 
+    h->info_valid_nq = -1;
     // fb_count restarts with every batch (it indexes this batch's fb_list); the statistics counters behind it were
     // zeroed once for the whole call (search_device_impl) and accumulate over the batches
     VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
@@ -649,6 +651,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         const int64_t total = nq * Dm;
         query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
             FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, 0});
+        h->info_valid_nq = nq;
         const int64_t threads = (Qp / 32) * h->ksteps * 64;
         build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(
             dq, nq, Dm, D4, h->ksteps, Qp / 32, info, ws.qpanels.as<half8>());
@@ -832,6 +835,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
             FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2,
                          use_i8 ? (1 | (h->i8_group == 8 ? 4 : 0)) : 0});
+        h->info_valid_nq = nq;
         if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
             ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
             const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vdb_ivf_set_centroids": (c_int, [c_void_p, c_void_p, c_int]),
     "vdb_ivf_get_centroids": (c_int, [c_void_p, c_void_p]),
     "vdb_ivf_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
+    "vdb_ivf_add_assigned": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "vdb_ivf_set_nprobe": (c_int, [c_void_p, c_int]),
     "vdb_ivf_get_assignment": (c_int, [c_void_p, c_void_p]),
     "vdb_ivf_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -80,11 +80,20 @@ class IVFFlatIndex:
         _ffi.check(self._lib.vdb_ivf_get_centroids(self._h, _ffi.ptr(out)))
         return out
 
-    def add(self, x: np.ndarray, id_base: int = 0) -> None:
+    def add(self, x: np.ndarray, id_base: int = 0, list_of_row: Optional[np.ndarray] = None) -> None:
+        """File the rows under the centroids.  `list_of_row` (int32, one list id per row, as `assignment()` returned it
+        for this corpus and these centroids) skips the nearest-centroid pass: what loading a persisted index does."""
         x = _ffi.as_f32_c(x)
         if x.ndim != 2 or x.shape[1] != self.dim:
             raise ValueError(f"expected (n, {self.dim}) vectors, got {x.shape}")
-        _ffi.check(self._lib.vdb_ivf_add(self._h, _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
+        if list_of_row is None:
+            _ffi.check(self._lib.vdb_ivf_add(self._h, _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
+        else:
+            lor = np.ascontiguousarray(list_of_row, dtype=np.int32)
+            if lor.shape != (x.shape[0],):
+                raise ValueError(f"expected {x.shape[0]} list ids, got {lor.shape}")
+            _ffi.check(self._lib.vdb_ivf_add_assigned(self._h, _ffi.ptr(x), x.shape[0], int(id_base), _ffi.ptr(lor)),
+                       build_time=True)
         self.ntotal = int(x.shape[0])
 
     def assignment(self) -> np.ndarray:
@@ -232,11 +241,11 @@ class HipApproximateSearch(BaseAlgorithm):
         centroids = np.load(path / manifest["files"]["centroids"])
         self.vectors = vectors
         self.index = IVFFlatIndex(self.dimension, int(manifest["nlist"]), self.metric, self.device)
-        self.index.set_centroids(centroids)       # no k-means: the stored quantizer is reused
-        self.index.add(vectors)                   # deterministic: reproduces the stored lists exactly
+        self.index.set_centroids(centroids)       # no k-means: the stored quantizer is reused ...
         stored = np.load(path / manifest["files"]["list_of_row"])
-        if not np.array_equal(stored, self.index.assignment()):
-            raise ValueError("Persisted inverted lists do not match the re-assigned corpus")
+        if stored.shape != (vectors.shape[0],) or (len(stored) and (stored.min() < 0 or stored.max() >= int(manifest["nlist"]))):
+            raise ValueError("Persisted inverted lists do not match the persisted corpus")
+        self.index.add(vectors, list_of_row=stored)   # ... and so are the stored lists: no assignment pass either
         self.index.set_nprobe(int(self.config.get("nprobe", manifest.get("nprobe", 1))))
         self.index_built = True
         metrics = {}
