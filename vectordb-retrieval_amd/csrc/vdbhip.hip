@@ -99,6 +99,8 @@ struct vdb_index_s {
     DevBuf panels8, bias8, rows8, rowstat8;  // rows8 / rowstat8: row-major int8 copy + {sum x^2, sum x} for the list refine
     int rows8_pitch = 0;
     bool i8_ok = false;
+    int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
+    int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
@@ -1442,6 +1444,12 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "upload_block_mb") {   // staging block of the row-block ingestion (0 = default 64 MiB)
             if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "upload_block_mb out of range");
             h->upload_block_mb = (int)value;
+        } else if (k == "ivf_bt") {
+            if (value != 0 && value != 4 && value != 16) throw Error(VDB_ERR_INVALID, "ivf_bt must be 0, 4 or 16");
+            h->ivf_bt = (int)value;
+        } else if (k == "ivf_nw") {
+            if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_nw must be 0, 2, 4 or 8");
+            h->ivf_nw = (int)value;
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
