@@ -547,3 +547,23 @@ def test_int8_copy_only_for_byte_valued_corpora(vdb):
         idx.add(X)
         assert idx.stats()["has_i8_copy"] == want
         idx.close()
+
+
+@pytest.mark.parametrize("kind", ["sift", "gauss"])
+def test_more_queries_than_one_pass_statistics_accumulate(vdb, oracle, kind):
+    """A call with more queries than one pass holds (16 384) is served in several passes: results are the same as the
+    oracle's on a sample from every pass, and vdb_stats reports the counters of the WHOLE call."""
+    X, _ = _make(70000, 128, 1, kind, 31)
+    _, Q = _make(1, 128, 40000, kind, 32)
+    idx = vdb.FlatIndex(128, "l2", 0)
+    idx.add(X)
+    D, I = idx.search(Q, 10)
+    st = idx.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["last_nq"] == 40000
+    assert st["scan_dtype"] == (1 if kind == "sift" else 0)
+    assert st["last_candidates"] >= 40000 * 5, st            # ~10 groups per query over ALL three passes, not the last one
+    sample = np.r_[0:8, 16380:16390, 32760:32776, 39990:40000]
+    Do, Io = oracle.knn(X, Q[sample], 10, "l2")
+    np.testing.assert_array_equal(I[sample], Io)
+    np.testing.assert_array_equal(D[sample], Do)
+    idx.close()

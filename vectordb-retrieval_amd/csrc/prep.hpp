@@ -248,11 +248,10 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
 
 // fp16 B-fragment panels of the query batch + padded float32 copy for the refine kernel.
 // thread per (qtile32, kstep, lane)
-__global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restrict__ Q, int64_t nq, int D, int D4,
-                                                            int ksteps, int64_t nqtiles,
-                                                            const QueryBatchInfo *__restrict__ info,
-                                                            half8 *__restrict__ qpanels) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void build_qpanels_body(int64_t gid, const float *__restrict__ Q, int64_t nq, int D, int D4,
+                                                   int ksteps, int64_t nqtiles,
+                                                   const QueryBatchInfo *__restrict__ info,
+                                                   half8 *__restrict__ qpanels) {
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
     const int ks = (int)(tk % ksteps);
@@ -270,6 +269,13 @@ __global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restr
         out[j] = (_Float16)v;
     }
     qpanels[gid] = out;
+}
+
+__global__ __launch_bounds__(256) void build_qpanels_kernel(const float *__restrict__ Q, int64_t nq, int D, int D4,
+                                                            int ksteps, int64_t nqtiles,
+                                                            const QueryBatchInfo *__restrict__ info,
+                                                            half8 *__restrict__ qpanels) {
+    build_qpanels_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, Q, nq, D, D4, ksteps, nqtiles, info, qpanels);
 }
 
 // B fragments for v_mfma_f32_16x16x32_f16: thread per (16-query block, 32-dim k-step, lane); lane l holds query
@@ -323,8 +329,7 @@ struct EpsArgs {
 
 // 16 lanes per query (coalesced row reads, shuffle reduction); the bound only needs ||q|| to ~1e-15 relative, the
 // 2 % slack below dwarfs the summation order.  Launch with ceil(nq / 16) * 16 lanes, 256 per block.
-__global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void query_eps_body(int64_t gid, const EpsArgs &a) {
     const int64_t q = gid >> 4;
     const int part = (int)(gid & 15);
     const bool qv = q < a.nq;
@@ -370,6 +375,10 @@ __global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
     double e = cs * eps_true * 1.02;
     if (!(e < 1.0e37)) e = 1.0e37;
     a.eps[q] = (float)e + 1.0e-30f;
+}
+
+__global__ __launch_bounds__(256) void query_eps_kernel(EpsArgs a) {
+    query_eps_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, a);
 }
 
 }  // namespace vdb

@@ -83,10 +83,9 @@ __global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restr
 
 // B fragments: qpanels8[qtile32][ks][lane][16 x int8], lane l holds query column l & 31, dims 32*ks + 16*(l>>5) .. +15,
 // value cq - q.  One thread per (qtile32, ks, lane).
-__global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int ks32,
-                                                               int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
-                                                               int4v *__restrict__ qpanels) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void build_qpanels_i8_body(int64_t gid, const float *__restrict__ Q, int64_t nq, int D, int ks32,
+                                                      int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
+                                                      int4v *__restrict__ qpanels) {
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
     const int ks = (int)(tk % ks32);
@@ -110,6 +109,12 @@ __global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__re
         out[w] = (int)word;
     }
     qpanels[gid] = out;
+}
+
+__global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int ks32,
+                                                               int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
+                                                               int4v *__restrict__ qpanels) {
+    build_qpanels_i8_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, Q, nq, D, ks32, nqtiles, info, qpanels);
 }
 
 // row-major int8 copy for the list refine (refine.hpp, RefineCommon.X8): rows[row][pitch] = x - cx, bytes beyond D hold
@@ -487,16 +492,46 @@ __global__ __launch_bounds__(256) void ivf_build_bias_i8_kernel(const float *__r
 }
 
 // int8 copy of the query rows, [nq][32*ks32] = cq - q; the items-mode scan gathers its B fragments from it
-__global__ __launch_bounds__(256) void ivf_qrows_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
-                                                           const QueryBatchInfo *__restrict__ info,
-                                                           signed char *__restrict__ qrows) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void qrows_i8_body(int64_t i, const float *__restrict__ Q, int64_t nq, int D, int Dpad,
+                                              const QueryBatchInfo *__restrict__ info, signed char *__restrict__ qrows) {
     const int mode = info->i8_mode;
     if (i >= nq * Dpad || !mode) return;
     const int64_t q = i / Dpad;
     const int d = (int)(i - q * Dpad);
     const int cq = (mode & 3) == 1 ? 127 : -1;
     qrows[i] = (signed char)(d < D ? cq - (int)Q[(size_t)q * D + d] : 0);
+}
+
+__global__ __launch_bounds__(256) void ivf_qrows_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
+                                                           const QueryBatchInfo *__restrict__ info,
+                                                           signed char *__restrict__ qrows) {
+    qrows_i8_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, Q, nq, D, Dpad, info, qrows);
+}
+
+// ONE dispatch for the per-batch query operands of the flat scan (each of the four kernels it replaces is a ~4.5 us
+// dispatch of its own): workgroups [0, nA) build the fp16 B fragments, [nA, nB) the int8 B fragments, [nB, nC) the
+// row-major int8 query rows for the list refine, [nC, nD) the per-query error bounds.
+struct QueryPrepArgs {
+    const float *Q;
+    int64_t nq, nqtiles;        // nqtiles: 32-query blocks (Qpad / 32)
+    int D, D4, ksteps, ks32, pitch8;
+    const QueryBatchInfo *info;
+    half8 *qpanels;
+    int4v *qpanels8;            // nullptr: no int8 scan offered
+    signed char *qrows8;        // nullptr: no int8 refine rows
+    EpsArgs eps;
+    unsigned nA, nB, nC;        // region boundaries in workgroups
+};
+__global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepArgs a) {
+    const unsigned b = blockIdx.x;
+    if (b < a.nA)
+        build_qpanels_body((int64_t)b * 256 + threadIdx.x, a.Q, a.nq, a.D, a.D4, a.ksteps, a.nqtiles, a.info, a.qpanels);
+    else if (b < a.nB)
+        build_qpanels_i8_body((int64_t)(b - a.nA) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.ks32, a.nqtiles, a.info, a.qpanels8);
+    else if (b < a.nC)
+        qrows_i8_body((int64_t)(b - a.nB) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.pitch8, a.info, a.qrows8);
+    else
+        query_eps_body((int64_t)(b - a.nC) * 256 + threadIdx.x, a.eps);
 }
 
 }  // namespace vdb

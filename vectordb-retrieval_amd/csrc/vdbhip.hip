@@ -115,6 +115,7 @@ struct vdb_index_s {
     // options
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
+    bool small_is_clean = false;             // ws.small was cleared for this call and no batch has used it yet
     int64_t info_valid_nq = -1;              // queries whose statistics the last search_batch left in batch_info(ws) (-1: none)
     bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
     bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
@@ -631,7 +632,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     h->info_valid_nq = -1;
     // fb_count restarts with every batch (it indexes this batch's fb_list); the statistics counters behind it were
     // zeroed once for the whole call (search_device_impl) and accumulate over the batches
-    VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
+    if (h->small_is_clean) h->small_is_clean = false;      // the first batch of a call: search_device_impl has just cleared all of it
+    else VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
     int32_t *fb_count = ws.small.as<int32_t>();
     unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 64);
 
@@ -838,23 +840,35 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
             FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2,
                          use_i8 ? (1 | (h->i8_group == 8 ? 4 : 0)) : 0});
         h->info_valid_nq = nq;
-        if (use_i8) {       // (returns at once unless the finalize kernel chose the int8 scan for this batch)
-            ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
-            const int64_t t8 = (Qpad / 32) * h->i8_ks * 64;
-            build_qpanels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
-                dq, nq, Dm, h->i8_ks, Qpad / 32, info, ws.qpanels8.as<int4v>());
-            if (rc.Q8)      // row-major int8 query rows for the list refine (refine.hpp)
-                ivf_qrows_i8_kernel<<<dim3((unsigned)((nq * h->rows8_pitch + 255) / 256)), dim3(256), 0, st>>>(
-                    dq, nq, Dm, h->rows8_pitch, info, ws.qrows8.as<signed char>());
-        }
-        const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
-        if (h->tile16)
-            build_qpanels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, h->ksteps / 2, Qpad / 16, info, ws.qpanels.as<half8>());
-        else
-            build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, h->ksteps, Qpad / 32, info, ws.qpanels.as<half8>());
         EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
                    h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
-        query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
+        const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
+        if (h->tile16) {
+            build_qpanels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, h->ksteps / 2, Qpad / 16, info, ws.qpanels.as<half8>());
+            query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
+        } else {            // one dispatch: fp16 fragments | int8 fragments | int8 query rows | error bounds (scan_i8.hpp)
+            QueryPrepArgs qp{};
+            qp.Q = dq; qp.nq = nq; qp.nqtiles = Qpad / 32;
+            qp.D = Dm; qp.D4 = D4; qp.ksteps = h->ksteps; qp.ks32 = h->i8_ks; qp.pitch8 = h->rows8_pitch;
+            qp.info = info;
+            qp.qpanels = ws.qpanels.as<half8>();
+            qp.eps = ea;
+            unsigned nblk = (unsigned)((threads + 255) / 256);
+            qp.nA = nblk;
+            if (use_i8) {   // (the int8 regions return at once unless the device chose the int8 scan for this batch)
+                ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
+                qp.qpanels8 = ws.qpanels8.as<int4v>();
+                nblk += (unsigned)(((Qpad / 32) * h->i8_ks * 64 + 255) / 256);
+            }
+            qp.nB = nblk;
+            if (use_i8 && rc.Q8) {
+                qp.qrows8 = ws.qrows8.as<signed char>();
+                nblk += (unsigned)((nq * h->rows8_pitch + 255) / 256);
+            }
+            qp.nC = nblk;
+            nblk += (unsigned)((nq * 16 + 255) / 256);
+            query_prep_kernel<<<dim3(nblk), dim3(256), 0, st>>>(qp);
+        }
         VDB_HIP(hipGetLastError());
     }
 
@@ -954,7 +968,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     se.fb_count = fb_count;
     se.stat_counters = stat_counters;
     const int nsb_i = G * g.nchunks;
-    if (nsb_i <= 256 && h->select_variant == 0 && !direct_rows) {  // multi-lane form: 16 lanes per query, 4 queries per wave
+    if (nsb_i > 128 && nsb_i <= 256 && h->select_variant == 2 && !direct_rows) {   // 32 lanes per query, 2 queries per wave
+        select_kernel_v2<8, 32><<<dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, st>>>(se);
+    } else if (nsb_i <= 256 && h->select_variant != 1 && !direct_rows) {  // multi-lane form: 16 lanes per query, 4 queries per wave
         const unsigned sgrid = (unsigned)((nq + 15) / 16);
         if (nsb_i <= 64)
             select_kernel_v2<4, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
@@ -1061,6 +1077,7 @@ void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, floa
     }
     h->ws.small.reserve(kSmallBytes);
     VDB_HIP(hipMemsetAsync(h->ws.small.p, 0, kSmallBytes, st));
+    h->small_is_clean = true;
     const size_t ev_mark = h->ev_used;
     try {
         for (int64_t b0 = 0; b0 < nq; b0 += kBatch) {
@@ -1071,8 +1088,10 @@ void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, floa
         }
     } catch (...) {
         h->ev_used = ev_mark;      // events of a failed search were never all recorded: do not leave them to vdb_stats
+        h->small_is_clean = false;
         throw;
     }
+    h->small_is_clean = false;
 }
 
 template <class F>
@@ -1476,7 +1495,8 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
             if (value < 0 || value > 4096) throw Error(VDB_ERR_INVALID, "spans_per_chunk out of range");
             h->spc_override = (int)value;
         } else if (k == "select_variant") {
-            h->select_variant = value != 0;
+            if (value < 0 || value > 2) throw Error(VDB_ERR_INVALID, "select_variant must be 0, 1 or 2");
+            h->select_variant = (int)value;
         } else if (k == "list_cap") {
             if (value < 0 || value > 65536) throw Error(VDB_ERR_INVALID, "list_cap out of range");
             h->list_cap = (int)value;
