@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-search kernel breakdown from a rocprofv3 --kernel-trace CSV of an IVF bench run: average device time of every
-kernel over the last 8 searches (from the coarse stage's query_stats_kernel to the fallback ivf_scan_kernel), the
+kernel over the last 8 searches (from the coarse stage's query_stats_kernel -- one per search: the list stage reuses its statistics -- to the fallback ivf_scan_kernel), the
 span of a search and the sum of its kernel times (the difference is launch gaps).
 Usage: python scripts/trace_breakdown.py <..._kernel_trace.csv>"""
 import collections, csv, sys
@@ -15,7 +15,7 @@ for s in sel:
     while i > 0:
         if "query_stats_kernel" in names[i]:
             cnt += 1
-            if cnt == 2:
+            if cnt == 1:
                 break
         i -= 1
     j = s
