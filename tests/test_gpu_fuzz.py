@@ -26,10 +26,14 @@ def _values(rng, kind, shape):
         return rng.standard_normal(shape) * (rng.random(shape) < 0.05)
     if kind == "offset":          # large common offset, small spread (cancellation in ||x||^2 - 2 q.x)
         return 50.0 + rng.standard_normal(shape) * 0.1
+    if kind == "bytes":           # the whole uint8 range: int8 scan copy, largest accumulator magnitudes
+        return rng.integers(0, 256, size=shape).astype(np.float64)
+    if kind == "sbytes":          # the whole int8 range (s8 window)
+        return rng.integers(-128, 128, size=shape).astype(np.float64)
     raise AssertionError(kind)
 
 
-KINDS = ["gauss", "ints", "bigints", "tiny", "huge", "heavy", "sparse", "offset"]
+KINDS = ["gauss", "ints", "bigints", "tiny", "huge", "heavy", "sparse", "offset", "bytes", "sbytes"]
 
 
 def _cases():

@@ -362,8 +362,9 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 if (cnt < a.k) ans |= (1u << bit);
             }
         }
-        const float that = select_threshold(unsortable_f32(ans), a.eps[q], a.info->i8_mode);
-        const int grows = group_rows_of(a.info->i8_mode);    // rows per candidate group (4, or 8 on the int8 scan)
+        const int i8_mode = a.info->i8_mode;                 // (read ONCE: in the loop below every use would be a fresh global load)
+        const float that = select_threshold(unsortable_f32(ans), a.eps[q], i8_mode);
+        const int grows = group_rows_of(i8_mode);            // rows per candidate group (4, or 8 on the int8 scan)
         if (!(that < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
@@ -388,13 +389,13 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     const int end = a.span_row0[pspan] + a.span_valid[pspan];
                     if (row1 > end) row1 = end;
                     c1 = true;
-                    crow1 = row0 + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
+                    crow1 = row0 + cand_row_offset(__float_as_uint(m1), i8_mode);
                     if (m2 <= that) {
                         if (a.bin_m3[base + ei] <= that) {
                             resc = true;
                         } else {
                             c2 = true;
-                            crow2 = row0 + cand_row_offset(__float_as_uint(m2), a.info->i8_mode);
+                            crow2 = row0 + cand_row_offset(__float_as_uint(m2), i8_mode);
                         }
                     }
                     if (resc || crow1 + grows > end || (c2 && crow2 + grows > end)) {

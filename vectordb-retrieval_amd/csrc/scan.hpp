@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         if (cnt < a.k) ans |= (1u << bit);
     }
     const float tau = unsortable_f32(ans);
-    const float that = select_threshold(tau, a.eps[q], a.info->i8_mode);
+    const int i8_mode = a.info->i8_mode;              // (read ONCE: inside the loops below every use would be a fresh global load)
+    const float that = select_threshold(tau, a.eps[q], i8_mode);
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
 
     int ncand = 0, nres = 0;  // wave-uniform
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                 const unsigned long long smask = __ballot(single), rmask = __ballot(deep);
                 if (single) {
                     const int pos = ncand + __popcll(smask & lt_mask);
-                    if (pos < a.cand_cap) cr[pos] = row0 + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
+                    if (pos < a.cand_cap) cr[pos] = row0 + cand_row_offset(__float_as_uint(m1), i8_mode);
                 }
                 if (deep) {
                     const int pos = nres + __popcll(rmask & lt_mask);
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             if (single) {
                 const int pos = ncand + __popcll(smask & lt_mask);
                 const int hh = s % a.groups;
-                const int row = (sspan * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
+                const int row = (sspan * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), i8_mode);
                 if (pos < a.cand_cap) cr[pos] = row;
             }
             ncand += __popcll(smask);
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if (cand) {
                         const int pos = ncand + __popcll(cm & lt_mask);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), a.info->i8_mode));
+                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), i8_mode));
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
@@ -829,7 +830,8 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
         if (cnt < a.k) ans |= (1u << bit);
     }
     const float tau = unsortable_f32(ans);
-    const float that = select_threshold(tau, qvalid ? a.eps[q] : 0.f, a.info->i8_mode);
+    const int i8_mode = a.info->i8_mode;              // (read ONCE, see select_kernel)
+    const float that = select_threshold(tau, qvalid ? a.eps[q] : 0.f, i8_mode);
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
     __syncthreads();  // counters zeroed
     int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1], *cnt_d = &s_cnt[wave][qi][2];
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
-                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), a.info->i8_mode);
+                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), i8_mode);
             } else {               // two or more interesting scores: queue the superbin for the cooperative walk below
                 const int pos = atomicAdd(cnt_d, 1);
                 if (pos < kDeepCap) deep[pos] = s;
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                 } else {
                     const int pos = atomicAdd(cnt_c, 1);
                     if (pos < a.cand_cap)
-                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), a.info->i8_mode));
+                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), i8_mode));
                 }
             }
         }
