@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
 // per step instead of VPL, and the few extra rows U lets through are re-scored in lanes that would idle anyway.
 // 4 queries per workgroup; LDS holds only the candidate lists.
 template <int KPL, int VPL>
-__global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a) {
+__global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_select_reg_kernel(DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
     constexpr int M = KPL <= 1 ? 2 : (2 * KPL <= VPL ? 2 * KPL : VPL);     // 64*M >= 2k: k <= 64*KPL
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void dense_select_reg_kernel(DenseSelectArgs a
         const int64_t row = valid ? (int64_t)cands[i] : 0;
         valid = valid && row < a.c.N;
         uint64_t key = ~0ull;
-        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        if (valid) key = exact_key<4>(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);   // (4: fewer VGPRs, 8 waves per SIMD)
         tk.offer(key, a.c.id_base + row, valid);
     }
     const size_t o = (size_t)q * k + ncert;

@@ -33,13 +33,15 @@ struct RefineCommon {
 
 typedef int refine_int4 __attribute__((ext_vector_type(4)));
 
+// U: float4 pairs in flight per lane (16 for the gather-bound refine kernels; kernels that want occupancy pass 4)
+template <int U = 16>
 __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const float *__restrict__ q, int D4,
                                               int metric) {
     const float4 *xv = reinterpret_cast<const float4 *>(x);
     const float4 *qv = reinterpret_cast<const float4 *>(q);
     double acc = 0.0;
     if (metric == 0) {
-#pragma unroll 16
+#pragma unroll U
         for (int i = 0; i < D4 / 4; ++i) {
             const float4 a = xv[i];
             const float4 b = qv[i];
@@ -51,7 +53,7 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
         }
         return sortable_u64(acc);
     } else {
-#pragma unroll 16
+#pragma unroll U
         for (int i = 0; i < D4 / 4; ++i) {
             const float4 a = xv[i];
             const float4 b = qv[i];
