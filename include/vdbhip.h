@@ -65,7 +65,7 @@ typedef struct vdb_stats_s {
     int32_t last_path;         /* enum vdb_path */
     int32_t corpus_fp16_exact; /* 1 if every corpus value is exactly representable in the fp16 scan copy */
     int64_t last_nq;
-    int64_t last_candidates;   /* candidate quads (4 consecutive rows each) re-scored exactly in the last search */
+    int64_t last_candidates;   /* candidate groups (4 consecutive rows each; 8 on the flat int8 scan) re-scored exactly */
     int64_t last_rescan_bins;  /* 256-row bins re-scanned exactly (collision guard) */
     int64_t last_fallback_queries; /* queries whose work list overflowed -> exhaustive exact scan */
     float last_scan_ms;        /* mean HIP-event time of the dominant (scan) kernel over the searches recorded since
@@ -163,8 +163,12 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * "panel_layout" (0 auto: 16-row-tile panels for D > 128; 1: 32-row tiles for every D; 2: 16-row tiles for every D;
  * takes effect at the next vdb_add), "panel_dtype" (0 auto: byte-valued integer corpora are ALSO kept as an int8 scan
  * copy and integer query batches in the byte window are scanned with int8 MFMA; 1: fp16 scan only).
- * "scan_variant" and the other A/B knobs exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped library
- * rejects them. */
+ * Tuning knobs whose every setting returns exact results (scripts/sweep_*.py): "i8_variant" (0..5: tile / stage / wave
+ * shapes of the int8 scan), "i8_group" (8 or 4 rows per select group of the flat int8 scan), "ivf_nw" (0 auto, 2 / 4 / 8
+ * waves per IVF work item), "ivf_bt" (0 auto, 4 / 16 tiles per IVF bin), "select_variant" (0..2), "upload_block_mb"
+ * (staging block of the row-block ingestion, default 64).
+ * "scan_variant" and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped
+ * library rejects them. */
 int vdb_set_option(vdb_handle h, const char *key, double value);
 
 /* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */

@@ -231,11 +231,15 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
     if (threadIdx.x == 0) {  // one set of atomics per workgroup
         amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
         flags = s_flags[0] | s_flags[1] | s_flags[2] | s_flags[3];
-        atomic_max_bits(&info->absmax_bits, amax);
-        if (flags & 1) atomic_set_flag(&info->nonfinite);
-        if (flags & 2) atomic_set_flag(&info->not_integer);
-        if (flags & 6) atomic_set_flag(&info->not_u8);
-        if (flags & 10) atomic_set_flag(&info->not_s8);
+        // (returning forms, results consumed below: a returned atomic has been performed at the coherence point)
+        unsigned seen = 0;
+        const unsigned ab = __float_as_uint(fabsf(amax));
+        if (ab > *reinterpret_cast<volatile unsigned *>(&info->absmax_bits)) seen += atomicMax(&info->absmax_bits, ab);
+        if ((flags & 1) && *reinterpret_cast<volatile int *>(&info->nonfinite) == 0) seen += (unsigned)atomicOr(&info->nonfinite, 1);
+        if ((flags & 2) && *reinterpret_cast<volatile int *>(&info->not_integer) == 0) seen += (unsigned)atomicOr(&info->not_integer, 1);
+        if ((flags & 6) && *reinterpret_cast<volatile int *>(&info->not_u8) == 0) seen += (unsigned)atomicOr(&info->not_u8, 1);
+        if ((flags & 10) && *reinterpret_cast<volatile int *>(&info->not_s8) == 0) seen += (unsigned)atomicOr(&info->not_s8, 1);
+        asm volatile("" ::"v"(seen));
         // The workgroup that arrives last fixes the scales: no separate one-thread kernel (a ~5 us dispatch) between the
         // statistics and their consumers.  Every contribution is an agent-scope atomic (performed at the coherence point,
         // never parked in this XCD's L2) and query_finalize reads with agent-scope atomic loads, so waiting for this

@@ -141,8 +141,8 @@ struct vdb_index_s {
     int64_t ivf_pspans = 0;
     int ivf_max_pspans = 0;
     DevBuf ivf_list_pspan0, ivf_span_row0, ivf_span_valid;
-    DevBuf ivf_cnt, ivf_cursor, ivf_slot_off, ivf_list_item0, ivf_item_list, ivf_item_slot0, ivf_item_bin0, ivf_plan,
-        ivf_slot_query, ivf_slot_of;
+    DevBuf ivf_cnt /* per-list counts | cursors | slot -> query map: one buffer, one memset */, ivf_slot_off, ivf_list_item0,
+        ivf_item_list, ivf_item_slot0, ivf_item_bin0, ivf_plan, ivf_slot_of;
 };
 
 namespace {
@@ -907,22 +907,20 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         s8.sb_m1 = sa.sb_m1; s8.sb_m2 = sa.sb_m2; s8.sb_span = sa.sb_span;
         s8.nspans = g.nspans; s8.Npad = h->Npad; s8.Qpad = Qpad; s8.nq_valid = nq;
         s8.spans_per_chunk = g.spc; s8.chunk_rem = g.rem; s8.nchunks = g.nchunks;
-        // i8_variant (tuning, every variant exact): 0 = 512-query tiles / 4-tile stages, 1 = 8-tile stages,
-        // 2 = 1024-query tiles (4 column blocks per wave), 3 = both
+        // i8_variant (tuning, every variant exact; scripts/sweep_i8.py): 0 = 512-query tiles (2 column blocks per wave),
+        // 4-tile stages; 1 = 8-tile stages; 2 = 1024-query tiles (4 column blocks per wave); 3 = both (default);
+        // 4 / 5 = 16 waves per workgroup (4 per SIMD) with 8- / 16-tile stages.  Odd batch sizes keep 512-query tiles.
+        int v8 = h->i8_variant;
 #ifdef VDB_ABLATIONS
-        s8.abl_no_bins = (h->i8_variant & 4) ? 1 : 0;
+        s8.abl_no_bins = (v8 & 8) ? 1 : 0;      // +8: no level-1 bin stores (timing only, WRONG results)
+        v8 &= 7;
 #endif
-        int v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 7) : (h->i8_variant & 1);
-#ifdef VDB_ABLATIONS
-        v8 = (Qpad % 1024 == 0) ? (h->i8_variant & 3) : (h->i8_variant & 1);
-#endif
-        if (v8 > 5) v8 = 3;
+        if (Qpad % 1024 != 0) v8 &= 1;
         const int qtile = (v8 >= 2) ? 1024 : 512;
         s8.nqtiles = (int)(Qpad / qtile);
         const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
 #define VDB_I8G(KS_, ST_, CB_, NW_, G_) scan_i8_kernel<KS_, ST_, CB_, NW_, 16, false, G_><<<grid8, dim3(NW_ * 64), 0, st>>>(s8)
 #define VDB_I8(KS_, ST_, CB_, NW_) do { if (h->i8_group == 8) VDB_I8G(KS_, ST_, CB_, NW_, 8); else VDB_I8G(KS_, ST_, CB_, NW_, 4); } while (0)
-        // variants 4, 5: 16 / 12... 16 waves per workgroup = 4 per SIMD, 64 queries each (1024-query tiles), rolled tile loop
         if (h->i8_ks == 2) {
             switch (v8) { case 1: VDB_I8(2, 8, 2, 8); break; case 2: VDB_I8(2, 4, 4, 8); break; case 3: VDB_I8(2, 8, 4, 8); break;
                           case 4: VDB_I8(2, 8, 2, 16); break; case 5: VDB_I8(2, 16, 2, 16); break; default: VDB_I8(2, 4, 2, 8); }
@@ -1166,8 +1164,8 @@ int vdb_destroy(vdb_handle h) {
         (void)hipDeviceSynchronize();
         DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
-                         &h->ivf_cnt, &h->ivf_cursor, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
-                         &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_query, &h->ivf_slot_of};
+                         &h->ivf_cnt, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
+                         &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
         for (auto b : all) b->release();
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
@@ -1474,7 +1472,7 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
             h->i8_group = (int)value;
         } else if (k == "i8_variant") {
 #ifdef VDB_ABLATIONS
-            if (value < 0 || value > 7) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..7");     // +4: no bin stores (timing only)
+            if (value < 0 || (((int)value) & 7) > 5 || value > 13) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5 (+8)");
 #else
             if (value < 0 || value > 5) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5");
 #endif
