@@ -448,6 +448,26 @@ def main() -> int:
         _, ie = flat.search(Q, k)
         flat.close()
         out["recall@10_vs_exact"] = round(recall_vs(ie, gpu_ids, k), 6)
+        if not args.no_cpu_baseline:
+            # CPU leg of config 4 ("vs FAISS-CPU": faiss is not installed, so the C restatement of the same IVF-Flat
+            # search -- same centroids, same lists, OpenMP over queries -- on a bounded query sample; its ids double as
+            # a bit-level check of the GPU result)
+            from oracle import c_oracle
+
+            c_oracle.build()
+            C, lor = index.centroids(), index.assignment()
+            probe = 256
+            t1 = time.perf_counter()
+            c_oracle.ivf_search(X, C, lor, Q[:probe], k, args.nprobe, metric)
+            dt = time.perf_counter() - t1
+            sample = int(min(nq, max(probe, probe * 8.0 / max(dt, 1e-6))))
+            t1 = time.perf_counter()
+            _, io_ = c_oracle.ivf_search(X, C, lor, Q[:sample], k, args.nprobe, metric)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "queries/s", "cores": c_oracle.num_threads(),
+                                   "kind": "port", "impl": "oracle/ivf_oracle.c (canonical float64 list scan, OpenMP)",
+                                   "sample": f"first {sample} of {nq} queries, nprobe {args.nprobe}, {dt:.1f} s"}
+            out["ids_equal_cpu_oracle_sample"] = bool(np.array_equal(io_, gpu_ids[:sample]))
     if X is None:
         out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, rank * n), 6)
     elif rank == 0 and world == 1 and not ivf:
