@@ -183,6 +183,49 @@ def timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch)
     return elapsed, st
 
 
+def scaling_reference_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup):
+    """The N > 1 default workload (one config-5 shard, 12.5M x 768 inner product) on ONE GPU through the sharded code
+    path (partial lists -> packed buffer -> merge; the all-gather of a one-rank world is a copy): the N = 1 point of
+    the weak-scaling series, in the same run as the headline."""
+    name = "marco12.5m"
+    n, d, nq, k, metric, _ = WORKLOADS[name]
+    _, Q, _, _ = make_data(name, 0)
+    X_t = device_rows(n, d, 0, dev)
+    index = vdbhip.FlatIndex(d, metric, local_rank)
+    index.add_device(X_t.data_ptr(), n, id_base=0)
+    q_t = torch.from_numpy(Q).to(dev)
+    D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    my_pack = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
+    all_pack = torch.empty((1, 2, nq, k), dtype=torch.int64, device=dev)
+
+    def step():
+        index.search_partial_device(q_t.data_ptr(), nq, k, my_pack[0].data_ptr(), my_pack[1].data_ptr(), stream)
+        all_pack.copy_(my_pack.unsqueeze(0))
+        vdbhip.merge_packed_partials_device(metric, local_rank, all_pack.data_ptr(), 1, nq, k,
+                                            D_t.data_ptr(), I_t.data_ptr(), stream)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    index.set_option("timing", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = index.stats()
+    leg = {"value": round(nq * steps / el, 1), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(el / steps * 1e3, 4),
+           "config": f"{name}: {n} rows x {d} dims, {nq} queries, k={k}, {metric}; rows generated on device",
+           "roofline": roofline_of(st, nq, n, d, name),
+           "recall@10_vs_float64_torch_sample": round(device_check(X_t, q_t, I_t, k, metric, 0), 6),
+           "note": "N = 1 point of the weak-scaling series: `bench.py --gpus N` (N > 1) runs this shard on every GPU "
+                   "and reports value = N x queries / time, so value(N) / (N x this value) is the scaling efficiency"}
+    index.close()
+    return leg
+
+
 def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
     """MFMA roofline of the dominant kernel from the HIP-event time the library recorded on the search stream."""
     scan_ms = float(st["last_scan_ms"])
@@ -438,6 +481,9 @@ def main() -> int:
     if world > 1 or sharded:
         out["qps_whole_corpus"] = round(nq * args.steps / elapsed, 1)
         out["shard_scan_alone_ms"] = round(shard_alone_ms, 4) if shard_alone_ms else None
+        out["scaling_reference"] = ("the N = 1 point of this workload is `also[\"%s\"].value` of the `--gpus 1` line (or "
+                                    "`--gpus 1 --workload %s`): the default N = 1 workload is sift1m, a different "
+                                    "problem" % (workload, workload))
 
     gpu_ids = I_t.cpu().numpy()
     if GT is not None:
@@ -491,6 +537,9 @@ def main() -> int:
                 "ids_equal_cpu_oracle_first32": bool(np.array_equal(I_t[:32].cpu().numpy(), io_))}}
             gi.close()
             del Xg, Qg
+            index.close()
+            out["also"]["marco12.5m"] = scaling_reference_leg(vdbhip, torch, dev, local_rank, stream,
+                                                              min(args.steps, 10), min(args.warmup, 2))
         if not args.no_cpu_baseline:
             legs, recall = cpu_baselines(X, Q, k, metric, gpu_ids)
             out["cpu_baseline"] = legs["blas_gemm_expansion"]

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Small-batch (serving-shaped) latency of the device-resident flat search on SIFT1M-shaped data: wall time of one
+`search_device` + stream synchronise for nq = 1 ... 512, median of 30.  Under `rocprofv3 --kernel-trace` with `--nq N`
+the trace holds only that batch size (scripts/trace_flat.py gives the per-kernel breakdown).
+Usage: python scripts/latency_serving.py [--nq N] [--kind sift|gaussian]"""
+import argparse, json, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "vectordb-retrieval_amd")]
+import numpy as np, torch, vdbhip
+from vdbhip import datasets
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nq", type=int, default=0)
+ap.add_argument("--kind", default="sift")
+ap.add_argument("--k", type=int, default=10)
+a = ap.parse_args()
+if a.kind == "sift":
+    X, Q = datasets.sift_like(1_000_000, 512, 128, 1234)
+else:
+    rng = np.random.default_rng(5)
+    X, Q = rng.standard_normal((1_000_000, 128), dtype=np.float32), rng.standard_normal((512, 128), dtype=np.float32)
+idx = vdbhip.FlatIndex(128, "l2", 0)
+idx.add(X)
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+q_t = torch.from_numpy(Q).to(dev)
+for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):
+    D_t = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
+    ts = []
+    for it in range(40):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx.search_device(q_t.data_ptr(), nq, a.k, D_t.data_ptr(), I_t.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    st = idx.stats()
+    print(json.dumps({"kind": a.kind, "nq": nq, "k": a.k, "median_us": round(float(np.median(ts[10:])) * 1e6, 1),
+                      "min_us": round(min(ts[10:]) * 1e6, 1), "path": st["last_path_name"],
+                      "scan_dtype": int(st.get("scan_dtype", 0))}), flush=True)
