@@ -209,7 +209,7 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // mode (one inverted list x one group of query slots, bins laid out [item][slot][bin], third minimum kept); G: rows per
 // select group (must match bit 2 of QueryBatchInfo.i8_mode, which the select and refine kernels read).
 template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8>
-__global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : 2)) void scan_i8_kernel(ScanI8Args a) {
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage

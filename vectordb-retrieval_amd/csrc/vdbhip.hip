@@ -102,6 +102,7 @@ struct vdb_index_s {
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 2048 queries keep the batch-shaped grid
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
@@ -395,7 +396,9 @@ struct ScanGeom {
     int spc = 0, rem = 0, nchunks = 0, vpl = 0;
 };
 
-ScanGeom scan_geometry(const vdb_index_s *h, int k) {
+// nq: queries of the batch.  Small batches (serving-shaped: one or a few 512-query tiles) take FINER chunks, so that the
+// grid still covers the chip: at 8192 rows per chunk a 1M-row corpus gives 128 workgroups per query tile, half the CUs.
+ScanGeom scan_geometry(const vdb_index_s *h, int k, int64_t nq) {
     ScanGeom g;
     const int G = h->tile16 ? 4 : 2;                        // bins (lane groups) per span
     g.nspans = h->Npad / (G * kBinRows);
@@ -404,7 +407,12 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k) {
     int64_t spc_hi = g.nspans * G / (4 * (int64_t)k);       // nsb >= 4k
     int64_t spc_lo = (g.nspans * G + 1023) / 1024;          // nsb <= 1024
     if (spc_hi < 1 || spc_hi < spc_lo) return g;
-    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : 32 / G, spc_hi);   // 8192 rows per chunk
+    int64_t spc_want = 32 / G;                              // 8192 rows per chunk
+    if (nq <= 2048 && !h->small_batch_off) {                // >= ~512 workgroups: chunks x query tiles
+        const int64_t nqt = (nq + 511) / 512;
+        spc_want = std::max<int64_t>(1, std::min<int64_t>(spc_want, g.nspans * nqt / 512));
+    }
+    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : spc_want, spc_hi);
     spc = std::max<int64_t>(spc, spc_lo);
     if (spc < 2 && g.nspans * G >= 128) spc = std::min<int64_t>(2, spc_hi);
     int64_t nchunks = (g.nspans + spc - 1) / spc;
@@ -463,7 +471,15 @@ constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {4, 4, 2}, {8, 4, 2}, {8, 4,
 [[maybe_unused]] constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
 
 template <int KSTEPS>
-void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16) {
+void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16, int nw = 8) {
+    if (bt == 16 && variant == 0 && nw < 8) {   // small batch: 64 * nw queries per workgroup, only the tiles that hold queries
+        sa.nqtiles = (int)((sa.nq_valid + nw * 64 - 1) / (nw * 64));
+        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
+        if (nw == 1) scan_kernel<KSTEPS, 1, 4, 1><<<dim3(grid), dim3(64), 0, st>>>(sa);
+        else if (nw == 2) scan_kernel<KSTEPS, 2, 4, 1><<<dim3(grid), dim3(128), 0, st>>>(sa);
+        else scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa);
+        return;
+    }
     if (bt != 16) {            // direct-bin mode: finer level-1 bins (8 or 4 tiles), production schedule only
         sa.nqtiles = (int)(Qpad / 512);
         const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
@@ -490,7 +506,7 @@ void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStre
     }
 }
 
-void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int direct_rows = 0) {
+void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int direct_rows = 0, int nw = 8) {
     const int bt = direct_rows ? direct_rows / 16 : 16;       // 32-row-tile layout: tiles per level-1 bin
     if (h->ksteps > kMaxKSteps) {  // D > 128
         // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
@@ -555,9 +571,9 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
             scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
         }
     } else if (h->ksteps == 4)
-        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st, bt);
+        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st, bt, nw);
     else
-        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st, bt);
+        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st, bt, nw);
     VDB_HIP(hipGetLastError());
 }
 
@@ -618,7 +634,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     bool use_scan = h->scan_ok && !exact_only && k <= 1024;
     int direct_rows = 0;
     if (use_scan) {
-        g = scan_geometry(h, k);
+        g = scan_geometry(h, k, nq);
         if (!g.ok) direct_rows = scan_geometry_direct(h, k, g);
     }
     // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
@@ -896,7 +912,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         h->dbg_words = nblocks * 8 * 8;
     }
     timing_mark(h, tslot, 0, st);
-    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows);       // (fp16: returns at once when the int8 scan serves the batch)
+    // small batches: as many waves per workgroup as there are 64-query column groups (1, 2, 4; 8 = the batch shape)
+    const int nw_small = h->small_batch_off ? 8 : nq <= 64 ? 1 : nq <= 128 ? 2 : nq <= 256 ? 4 : 8;
+    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows, nw_small);   // (fp16: returns at once when the int8 scan serves the batch)
     if (use_i8) {
         ScanI8Args s8{};
         s8.panels = h->panels8.as<int4v>();
@@ -916,17 +934,22 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         v8 &= 7;
 #endif
         if (Qpad % 1024 != 0) v8 &= 1;
-        const int qtile = (v8 >= 2) ? 1024 : 512;
-        s8.nqtiles = (int)(Qpad / qtile);
+        if (nw_small < 8) v8 = 8 + nw_small;
+        const int qtile = (v8 > 8) ? 64 * nw_small : (v8 >= 2) ? 1024 : 512;
+        s8.nqtiles = (int)((v8 > 8 ? nq + qtile - 1 : Qpad) / qtile);
         const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
 #define VDB_I8G(KS_, ST_, CB_, NW_, G_) scan_i8_kernel<KS_, ST_, CB_, NW_, 16, false, G_><<<grid8, dim3(NW_ * 64), 0, st>>>(s8)
 #define VDB_I8(KS_, ST_, CB_, NW_) do { if (h->i8_group == 8) VDB_I8G(KS_, ST_, CB_, NW_, 8); else VDB_I8G(KS_, ST_, CB_, NW_, 4); } while (0)
         if (h->i8_ks == 2) {
             switch (v8) { case 1: VDB_I8(2, 8, 2, 8); break; case 2: VDB_I8(2, 4, 4, 8); break; case 3: VDB_I8(2, 8, 4, 8); break;
-                          case 4: VDB_I8(2, 8, 2, 16); break; case 5: VDB_I8(2, 16, 2, 16); break; default: VDB_I8(2, 4, 2, 8); }
+                          case 4: VDB_I8(2, 8, 2, 16); break; case 5: VDB_I8(2, 16, 2, 16); break;
+                          case 9: VDB_I8(2, 4, 2, 1); break; case 10: VDB_I8(2, 4, 2, 2); break; case 12: VDB_I8(2, 4, 2, 4); break;
+                          default: VDB_I8(2, 4, 2, 8); }
         } else {
             switch (v8) { case 1: VDB_I8(4, 8, 2, 8); break; case 2: VDB_I8(4, 4, 4, 8); break; case 3: VDB_I8(4, 8, 4, 8); break;
-                          case 4: VDB_I8(4, 8, 2, 16); break; case 5: VDB_I8(4, 16, 2, 16); break; default: VDB_I8(4, 4, 2, 8); }
+                          case 4: VDB_I8(4, 8, 2, 16); break; case 5: VDB_I8(4, 16, 2, 16); break;
+                          case 9: VDB_I8(4, 4, 2, 1); break; case 10: VDB_I8(4, 4, 2, 2); break; case 12: VDB_I8(4, 4, 2, 4); break;
+                          default: VDB_I8(4, 4, 2, 8); }
         }
 #undef VDB_I8G
 #undef VDB_I8
@@ -1467,6 +1490,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_nw") {
             if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_nw must be 0, 2, 4 or 8");
             h->ivf_nw = (int)value;
+        } else if (k == "small_batch") {       // 1 (default): finer chunks / narrower workgroups for batches <= 2048 queries
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "small_batch must be 0 or 1");
+            h->small_batch_off = value == 0;
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
