@@ -14,14 +14,21 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nq", type=int, default=0)
 ap.add_argument("--kind", default="sift")
 ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--ivf", type=int, default=0, help="IVF-Flat nlist = 1024 with this nprobe instead of the flat index")
 a = ap.parse_args()
 if a.kind == "sift":
     X, Q = datasets.sift_like(1_000_000, 512, 128, 1234)
 else:
     rng = np.random.default_rng(5)
     X, Q = rng.standard_normal((1_000_000, 128), dtype=np.float32), rng.standard_normal((512, 128), dtype=np.float32)
-idx = vdbhip.FlatIndex(128, "l2", 0)
-idx.add(X)
+if a.ivf:
+    idx = vdbhip.IVFFlatIndex(128, 1024, "l2", 0)
+    idx.train(X, niter=10, seed=1234, max_points_per_centroid=256)
+    idx.add(X)
+    idx.set_nprobe(a.ivf)
+else:
+    idx = vdbhip.FlatIndex(128, "l2", 0)
+    idx.add(X)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 q_t = torch.from_numpy(Q).to(dev)
@@ -36,6 +43,6 @@ for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     st = idx.stats()
-    print(json.dumps({"kind": a.kind, "nq": nq, "k": a.k, "median_us": round(float(np.median(ts[10:])) * 1e6, 1),
+    print(json.dumps({"kind": a.kind, "ivf_nprobe": a.ivf, "nq": nq, "k": a.k, "median_us": round(float(np.median(ts[10:])) * 1e6, 1),
                       "min_us": round(min(ts[10:]) * 1e6, 1), "path": st["last_path_name"],
                       "scan_dtype": int(st.get("scan_dtype", 0))}), flush=True)

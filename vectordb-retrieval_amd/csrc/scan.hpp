@@ -46,6 +46,7 @@ struct ScanArgs {
     const int32_t *item_bin0;    // [items] first level-1 bin of the item's output block
     const int32_t *n_items;      // [1]
     const int32_t *list_pspan0;  // [nlist+1] panel spans of every list (lists are padded to whole spans)
+    int part_spans;              // items mode: spans per row part (blockIdx.y = part of the list this workgroup scans; 0 = whole list)
     const int32_t *slot_query;   // [slots] query + 1 of every slot (0 = padding)
     const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
     unsigned long long *dbg;     // ABL == 4 (diagnostic build): per-wave cycle sums {head, mfma, select, barrier, total, late}
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     const bool late = (PRIO == 3) || ((NWAVES >= 2) && (wave >= NWAVES / 2));
     int chunk = 0;
     int64_t q0, span0, span1, out_pitch, out_col;
+    int64_t lspan0 = 0, lspans = 0;                         // items mode: first span / span count of the whole list (bin indexing)
     size_t bin_base = 0;                                    // first level-1 bin of this block's output
     if (ITEMS) {
         const int it = blockIdx.x;
@@ -188,6 +190,13 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         const int l = a.item_list[it];
         span0 = a.list_pspan0[l];
         span1 = a.list_pspan0[l + 1];
+        lspan0 = span0;
+        lspans = span1 - span0;
+        if (a.part_spans > 0) {      // long lists are cut into row parts, one workgroup each: same bins, shorter critical path
+            span0 += (int64_t)blockIdx.y * a.part_spans;
+            if (span0 >= span1) return;
+            if (span0 + a.part_spans < span1) span1 = span0 + a.part_spans;
+        }
         q0 = (int64_t)a.item_slot0[it] + wave * 64;        // "queries" are gathered query slots
         out_pitch = NWAVES * 64;
         out_col = wave * 64 + (lane & 31);
@@ -209,18 +218,11 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
 
     // ---- B fragments: resident for the whole chunk ------------------------------------------------
     half8 b0[KSTEPS], b1[KSTEPS];
-    if (ITEMS) {  // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's query row
-        const int qa = a.slot_query[q0 + (lane & 31)] - 1, qb = a.slot_query[q0 + 32 + (lane & 31)] - 1;
-        const half8 *ra = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (16 * KSTEPS)) + h;
-        const half8 *rb = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qb < 0 ? 0 : qb) * (16 * KSTEPS)) + h;
-        half8 zero;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            b0[ks] = qa < 0 ? zero : ra[ks * 2];
-            b1[ks] = qb < 0 ? zero : rb[ks * 2];
-        }
+    int qa = -1, qb = -1;
+    if (ITEMS) {  // the slots' queries now, their rows AFTER the first stage is on its way (gather_b below): a work item
+                  // is short, so every dependent round trip in front of its first MFMA counts
+        qa = a.slot_query[q0 + (lane & 31)] - 1;
+        qb = a.slot_query[q0 + 32 + (lane & 31)] - 1;
     } else {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     }
 
     const int nstages = (int)(span1 - span0) * SPS;
-    const int nb_item = (int)(span1 - span0) * 2 * BPS;    // ITEMS: bins per query slot in this item
+    const int nb_item = (int)lspans * 2 * BPS;    // ITEMS: bins per query slot in this item
 
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         // flat: [bin][query] (coalesced over the 32 queries of a lane half).  ITEMS: [item][slot][bin] so
         // that the per-query select reads the bins of one probe as one contiguous run.
         const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
-                                     (size_t)(((span - span0) * 2 + h) * BPS + bt)
+                                     (size_t)(((span - lspan0) * 2 + h) * BPS + bt)
                                : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
         const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
 #pragma unroll
@@ -305,6 +307,18 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     };
 
     stage_issue(0, 0);
+    if (ITEMS) {  // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's query row
+        const half8 *ra = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (16 * KSTEPS)) + h;
+        const half8 *rb = reinterpret_cast<const half8 *>(a.qrows + (size_t)(qb < 0 ? 0 : qb) * (16 * KSTEPS)) + h;
+        half8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            b0[ks] = qa < 0 ? zero : ra[ks * 2];
+            b1[ks] = qb < 0 ? zero : rb[ks * 2];
+        }
+    }
     stage_bias_store(0);
     __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
 

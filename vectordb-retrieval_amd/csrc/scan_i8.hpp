@@ -151,6 +151,7 @@ struct ScanI8Args {
     float *bin_m3;               // third-smallest quad minimum of each bin
     const int32_t *item_list, *item_slot0, *item_bin0, *n_items, *list_pspan0, *slot_query;
     const signed char *qrows;    // [nq][32*KS] int8 query rows cq - q (B fragments are gathered from them)
+    int part_spans;              // items mode: spans per row part (blockIdx.y), 0 = whole list (see ScanArgs)
     int abl_no_bins;             // -DVDB_ABLATIONS builds only (timing, WRONG results): skip the level-1 bin stores
 };
 
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     const bool late = (NWAVES >= 2) && (wave >= NWAVES / 2);
     int chunk = 0;
     int64_t q0, span0, span1, out_pitch, out_col;
+    int64_t lspan0 = 0, lspans = 0;                         // items mode: first span / span count of the whole list (bin indexing)
     size_t bin_base = 0;
     if (ITEMS) {
         const int it = blockIdx.x;
@@ -240,6 +242,13 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         const int l = a.item_list[it];
         span0 = a.list_pspan0[l];
         span1 = a.list_pspan0[l + 1];
+        lspan0 = span0;
+        lspans = span1 - span0;
+        if (a.part_spans > 0) {      // long lists are cut into row parts, one workgroup each: same bins, shorter critical path
+            span0 += (int64_t)blockIdx.y * a.part_spans;
+            if (span0 >= span1) return;
+            if (span0 + a.part_spans < span1) span1 = span0 + a.part_spans;
+        }
         q0 = (int64_t)a.item_slot0[it] + wave * 64;
         out_pitch = NWAVES * 64;
         out_col = wave * 64 + (lane & 31);
@@ -260,15 +269,10 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     const int32_t *bias = a.bias8 + ((mode & 3) == 1 ? 0 : a.Npad);
 
     int4v bq[CB][KS];
-    if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
+    int qslot[CB];
+    if (ITEMS) {   // the slots' queries now, their rows after the first stage is on its way (as scan_kernel)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const int qa = a.slot_query[q0 + cb * 32 + (lane & 31)] - 1;      // (0 = padding slot)
-            const int4v *ra = reinterpret_cast<const int4v *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (32 * KS)) + h;
-            const int4v zero = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = qa < 0 ? zero : ra[ks * 2];
-        }
+        for (int cb = 0; cb < CB; ++cb) qslot[cb] = a.slot_query[q0 + cb * 32 + (lane & 31)] - 1;      // (0 = padding slot)
     } else {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KS + ks) * 64 + lane];
     }
     const int nstages = (int)(span1 - span0) * SPS;
-    const int nb_item = (int)(span1 - span0) * 2 * BPS;    // ITEMS: bins per query slot in this item
+    const int nb_item = (int)lspans * 2 * BPS;    // ITEMS: bins per query slot in this item
     const int INF = (int)kI8Inf;
     int m1[CB], m2[CB], m3[CB], M1[CB], M2[CB], Ms[CB];
 #pragma unroll
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]; ITEMS: [item][slot][bin]
     auto flush_bin = [&](int64_t span, int bt) {
         const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
-                                     (size_t)(((span - span0) * 2 + h) * BPS + bt)
+                                     (size_t)(((span - lspan0) * 2 + h) * BPS + bt)
                                : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
         const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
 #pragma unroll
@@ -346,6 +350,16 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     };
 
     stage_issue(0, 0);
+    if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int qa = qslot[cb];
+            const int4v *ra = reinterpret_cast<const int4v *>(a.qrows + (size_t)(qa < 0 ? 0 : qa) * (32 * KS)) + h;
+            const int4v zero = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = qa < 0 ? zero : ra[ks * 2];
+        }
+    }
     stage_bias_store(0);
     __syncthreads();
 
