@@ -166,7 +166,10 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * Tuning knobs whose every setting returns exact results (scripts/sweep_*.py): "i8_variant" (0..5: tile / stage / wave
  * shapes of the int8 scan), "i8_group" (8 or 4 rows per select group of the flat int8 scan), "ivf_nw" (0 auto, 2 / 4 / 8
  * waves per IVF work item), "ivf_bt" (0 auto, 4 / 16 tiles per IVF bin), "select_variant" (0..2), "upload_block_mb"
- * (staging block of the row-block ingestion, default 64), "small_batch" (1 default: batches of <= 2048 queries are
+ * (staging block of the row-block ingestion, default 64), "ivf_part" (0 auto: spans of 512 rows per row part of the IVF list scan -- long lists are
+ * cut into parts scanned by one workgroup each), "ivf_st" (0 auto, 2 / 4 / 8 tiles per LDS stage of the int8 list scan),
+ * "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
+ * scan), "small_batch" (1 default: batches of <= 2048 queries are
  * scanned with finer row chunks and, up to 256 queries, 1 / 2 / 4-wave workgroups so that the grid still covers the
  * chip; 0: the batch-shaped grid for every batch size).
  * "scan_variant" and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped

@@ -304,3 +304,45 @@ def test_int8_list_scan_bit_exact(vdb, oracle, metric, window, d):
     np.testing.assert_array_equal(I2, Io2)
     np.testing.assert_array_equal(D2, Do2)
     idx.close()
+
+
+@pytest.mark.parametrize("kind", ["bytes", "gauss"])
+def test_small_query_batches_and_row_parts_bit_exact(vdb, oracle, kind):
+    """Serving-shaped IVF batches (1 ... 65 queries) go through the list-major MFMA scan too (`ivf_min_batch`), the
+    coarse quantizer through the split exhaustive scan; long lists are scanned in row parts (`ivf_part`).  Skewed list
+    sizes (a third of the rows sit in four lists), every part size, the int8 and the fp16 list scan: the oracle's bits."""
+    rng = np.random.default_rng(17)
+    n, d, nlist, k = 120_000, 128, 96, 10
+    if kind == "bytes":
+        X = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(n, d))), 0, 255).astype(np.float32)
+        Q = np.clip(np.rint(rng.gamma(0.6, 40.0, size=(700, d))), 0, 255).astype(np.float32)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((700, d)).astype(np.float32)
+    X[: n // 3] = X[:4].repeat(n // 12, axis=0) + (np.rint(rng.uniform(-3, 3, (n // 3, d))) if kind == "bytes"
+                                                     else 0.05 * rng.standard_normal((n // 3, d))).astype(np.float32)
+    if kind == "bytes":
+        X = np.clip(X, 0, 255)
+    C = X[rng.choice(n, nlist, replace=False)] + rng.uniform(-0.25, 0.25, (nlist, d)).astype(np.float32)
+    C[:4] = X[:4]
+    idx = vdb.IVFFlatIndex(d, nlist, "l2", 0)
+    idx.set_centroids(C)
+    idx.add(X)
+    lor = idx.assignment()
+    assert np.bincount(lor, minlength=nlist).max() > 5 * n // nlist        # the skew is there
+    idx.set_nprobe(12)
+    Do, Io = oracle.ivf_search(X, C, lor, Q, k, 12, "l2")
+    for nq in (1, 3, 8, 63, 64, 65, 700):
+        for part in (0, 1, 3, 1024):
+            idx.set_option("ivf_part", part)
+            D, I = idx.search(Q[:nq], k)
+            st = idx.stats()
+            assert st["last_path_name"] == "ivf" and st["scan_dtype"] == (1 if kind == "bytes" else 0), (nq, part, st)
+            np.testing.assert_array_equal(I, Io[:nq], err_msg=f"nq={nq} ivf_part={part}")
+            np.testing.assert_array_equal(D, Do[:nq], err_msg=f"nq={nq} ivf_part={part}")
+    idx.set_option("ivf_part", 0)
+    idx.set_option("ivf_min_batch", 64)              # the exact list scan for small batches, as before: same bits
+    D, I = idx.search(Q[:8], k)
+    np.testing.assert_array_equal(I, Io[:8])
+    np.testing.assert_array_equal(D, Do[:8])
+    idx.close()

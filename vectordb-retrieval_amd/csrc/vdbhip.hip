@@ -102,6 +102,7 @@ struct vdb_index_s {
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
     int ivf_st = 0;                          // option "ivf_st": tiles per LDS stage of the int8 IVF scan (0 auto, 2 / 4 / 8)
     int ivf_part = 0;                        // option "ivf_part": spans per row part of the IVF list scan (0 auto)
+    int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 2048 queries keep the batch-shaped grid
@@ -786,6 +787,9 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         int64_t S = ((blocked ? 4096 : 8192) + ngroups - 1) / ngroups;
         // (a split is worth >= 1024 rows; the blocked form merges 4x the partial lists per unit, so its splits are larger)
         S = std::min<int64_t>(S, std::max<int64_t>(1, h->N / (blocked ? 2048 : 1024)));
+        // a handful of queries on a small corpus (an IVF coarse quantizer asked for 1..63 queries): one wave per query
+        // would walk all rows alone (92 us for 8 queries x 1024 centroids) -- up to 64 splits of >= 128 rows instead
+        if (!blocked && nq < 64) S = std::max<int64_t>(S, std::min<int64_t>(64, h->N / 128));
         const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
         S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
         RefineFullArgs fa{};
@@ -1495,6 +1499,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_part") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "ivf_part must be 0 (auto) or 1..1024 spans");
             h->ivf_part = (int)value;
+        } else if (k == "ivf_min_batch") {
+            if (value < 1 || value > 1e9) throw Error(VDB_ERR_INVALID, "ivf_min_batch must be >= 1");
+            h->ivf_min_batch = (int)value;
         } else if (k == "ivf_nw") {
             if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_nw must be 0, 2, 4 or 8");
             h->ivf_nw = (int)value;
