@@ -169,7 +169,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * (staging block of the row-block ingestion, default 64), "ivf_part" (0 auto: spans of 512 rows per row part of the IVF list scan -- long lists are
  * cut into parts scanned by one workgroup each), "ivf_st" (0 auto, 2 / 4 / 8 tiles per LDS stage of the int8 list scan),
  * "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
- * scan), "small_batch" (1 default: batches of <= 2048 queries are
+ * scan), "small_batch" (1 default: batches of <= 512 queries are
  * scanned with finer row chunks and, up to 256 queries, 1 / 2 / 4-wave workgroups so that the grid still covers the
  * chip; 0: the batch-shaped grid for every batch size).
  * "scan_variant" and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped

@@ -17,10 +17,10 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--ivf", type=int, default=0, help="IVF-Flat nlist = 1024 with this nprobe instead of the flat index")
 a = ap.parse_args()
 if a.kind == "sift":
-    X, Q = datasets.sift_like(1_000_000, 512, 128, 1234)
+    X, Q = datasets.sift_like(1_000_000, max(512, a.nq), 128, 1234)
 else:
     rng = np.random.default_rng(5)
-    X, Q = rng.standard_normal((1_000_000, 128), dtype=np.float32), rng.standard_normal((512, 128), dtype=np.float32)
+    X, Q = rng.standard_normal((1_000_000, 128), dtype=np.float32), rng.standard_normal((max(512, a.nq), 128), dtype=np.float32)
 if a.ivf:
     idx = vdbhip.IVFFlatIndex(128, 1024, "l2", 0)
     idx.train(X, niter=10, seed=1234, max_points_per_centroid=256)

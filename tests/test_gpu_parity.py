@@ -571,14 +571,14 @@ def test_more_queries_than_one_pass_statistics_accumulate(vdb, oracle, kind):
 
 @pytest.mark.parametrize("kind,d,metric", [("sift", 128, "l2"), ("gauss", 128, "l2"), ("glove", 50, "ip"), ("sift", 64, "ip")])
 def test_small_batches_use_narrow_workgroups_and_stay_exact(vdb, oracle, kind, d, metric):
-    """Serving-shaped batches: up to 2048 queries the scan takes finer row chunks, up to 256 queries 1 / 2 / 4-wave
+    """Serving-shaped batches: up to 512 queries the scan takes finer row chunks, up to 256 queries 1 / 2 / 4-wave
     workgroups (vdbhip.hip search_batch).  Every batch size on both sides of each threshold returns the oracle's bits,
     the same as the batch-shaped grid (`small_batch` = 0), for the int8 and the fp16 scan and both panel depths."""
     X, Q = _make(150_000, d, 2100, kind, 77)
     idx = vdb.FlatIndex(d, metric, 0)
     idx.add(X)
     Do, Io = oracle.knn(X, Q, 10, metric)
-    for nq in (1, 2, 63, 64, 65, 128, 129, 256, 257, 512, 513, 2048, 2049):
+    for nq in (1, 2, 63, 64, 65, 128, 129, 256, 257, 512, 513, 2049):
         for sb in (1, 0):
             idx.set_option("small_batch", sb)
             D, I = idx.search(Q[:nq], 10)

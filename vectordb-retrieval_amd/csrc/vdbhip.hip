@@ -105,7 +105,7 @@ struct vdb_index_s {
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
-    int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 2048 queries keep the batch-shaped grid
+    int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 512 queries keep the batch-shaped grid
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
     float absmax = 0.f, maxnorm2 = 0.f, sx = 1.f;
@@ -399,7 +399,7 @@ struct ScanGeom {
     int spc = 0, rem = 0, nchunks = 0, vpl = 0;
 };
 
-// nq: queries of the batch.  Small batches (serving-shaped: one or a few 512-query tiles) take FINER chunks, so that the
+// nq: queries of the batch.  Small batches (serving-shaped: up to one 512-query tile) take FINER chunks, so that the
 // grid still covers the chip: at 8192 rows per chunk a 1M-row corpus gives 128 workgroups per query tile, half the CUs.
 ScanGeom scan_geometry(const vdb_index_s *h, int k, int64_t nq) {
     ScanGeom g;
@@ -411,10 +411,8 @@ ScanGeom scan_geometry(const vdb_index_s *h, int k, int64_t nq) {
     int64_t spc_lo = (g.nspans * G + 1023) / 1024;          // nsb <= 1024
     if (spc_hi < 1 || spc_hi < spc_lo) return g;
     int64_t spc_want = 32 / G;                              // 8192 rows per chunk
-    if (nq <= 2048 && !h->small_batch_off) {                // >= ~512 workgroups: chunks x query tiles
-        const int64_t nqt = (nq + 511) / 512;
-        spc_want = std::max<int64_t>(1, std::min<int64_t>(spc_want, g.nspans * nqt / 512));
-    }
+    // (one query tile only: from 1024 queries on the batch shape is as fast or faster -- scripts/throughput_vs_batch.py)
+    if (nq <= 512 && !h->small_batch_off) spc_want = std::max<int64_t>(1, std::min<int64_t>(spc_want, g.nspans / 512));
     int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : spc_want, spc_hi);
     spc = std::max<int64_t>(spc, spc_lo);
     if (spc < 2 && g.nspans * G >= 128) spc = std::min<int64_t>(2, spc_hi);
@@ -1505,7 +1503,7 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_nw") {
             if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_nw must be 0, 2, 4 or 8");
             h->ivf_nw = (int)value;
-        } else if (k == "small_batch") {       // 1 (default): finer chunks / narrower workgroups for batches <= 2048 queries
+        } else if (k == "small_batch") {       // 1 (default): finer chunks / narrower workgroups for batches <= 512 queries
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "small_batch must be 0 or 1");
             h->small_batch_off = value == 0;
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
