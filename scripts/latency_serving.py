@@ -12,16 +12,26 @@ from vdbhip import datasets
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nq", type=int, default=0)
-ap.add_argument("--kind", default="sift")
+ap.add_argument("--kind", default="sift", help="sift | gaussian (1M x 128, l2) | marco (2M x 768, ip, rows generated on device)")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--ivf", type=int, default=0, help="IVF-Flat nlist = 1024 with this nprobe instead of the flat index")
 a = ap.parse_args()
-if a.kind == "sift":
+dev = torch.device("cuda", 0)
+if a.kind == "marco":
+    from bench import device_rows
+    X_t = device_rows(2_000_000, 768, 0, dev)
+    Q = np.random.default_rng(1235).standard_normal((max(512, a.nq), 768), dtype=np.float32)
+    idx = vdbhip.FlatIndex(768, "ip", 0)
+    idx.add_device(X_t.data_ptr(), 2_000_000, id_base=0)
+    torch.cuda.synchronize()
+elif a.kind == "sift":
     X, Q = datasets.sift_like(1_000_000, max(512, a.nq), 128, 1234)
 else:
     rng = np.random.default_rng(5)
     X, Q = rng.standard_normal((1_000_000, 128), dtype=np.float32), rng.standard_normal((max(512, a.nq), 128), dtype=np.float32)
-if a.ivf:
+if a.kind == "marco":
+    pass
+elif a.ivf:
     idx = vdbhip.IVFFlatIndex(128, 1024, "l2", 0)
     idx.train(X, niter=10, seed=1234, max_points_per_centroid=256)
     idx.add(X)
@@ -29,7 +39,6 @@ if a.ivf:
 else:
     idx = vdbhip.FlatIndex(128, "l2", 0)
     idx.add(X)
-dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 q_t = torch.from_numpy(Q).to(dev)
 for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):

@@ -594,3 +594,30 @@ def test_small_batches_use_narrow_workgroups_and_stay_exact(vdb, oracle, kind, d
     np.testing.assert_array_equal(I, Io50)
     np.testing.assert_array_equal(D, Do50)
     idx.close()
+
+
+@pytest.mark.parametrize("d,metric", [(768, "ip"), (384, "l2"), (200, "cosine"), (1600, "ip")])
+def test_small_batches_on_the_kloop_scan_stay_exact(vdb, oracle, d, metric):
+    """D > 128, serving-shaped batches: waves whose query columns are all padding only stage panels; below 64 queries the
+    one active wave works on the column blocks that hold queries; up to 16 queries (D <= 1536) its B fragments live in
+    LDS (scan16.hpp NARROW 1 / 2).  Batch sizes either side of every threshold against the oracle, and against the
+    batch-shaped kernel (`small_batch` = 0)."""
+    rng = np.random.default_rng(d)
+    n = 40_000
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((130, d)).astype(np.float32)
+    algo_metric = "ip" if metric == "cosine" else metric
+    if metric == "cosine":
+        X, Q = rs.safe_normalize(X), rs.safe_normalize(Q)
+    idx = vdb.FlatIndex(d, algo_metric, 0)
+    idx.add(X)
+    Do, Io = oracle.knn(X, Q, 10, algo_metric)
+    for nq in (1, 5, 16, 17, 33, 63, 64, 65, 130):
+        for sb in (1, 0):
+            idx.set_option("small_batch", sb)
+            D, I = idx.search(Q[:nq], 10)
+            st = idx.stats()
+            assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, (nq, sb, st)
+            np.testing.assert_array_equal(I, Io[:nq], err_msg=f"nq={nq} small_batch={sb}")
+            np.testing.assert_array_equal(D, Do[:nq], err_msg=f"nq={nq} small_batch={sb}")
+    idx.close()

@@ -215,14 +215,21 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(ScanArgs a) {
 // (k-step 0, tiles 0-3), (0, 4-7), (1, 0-3), (1, 4-7).  Eight passes complete the four 256-row bins of a span.
 // BS / ring / barrier placement / ABL builds: see scan_kloop_kernel.
 // FP: passes per level-1 bin (8: the 256-row bins (span, g); 4 / 2: 128- / 64-row bins for the direct-bin select).
-template <int ABL, int BS, int FP = 8>
+// NARROW (batches below 64 queries: one wave per workgroup holds queries, and it alone on its SIMD cannot hide a global
+// load per K-step behind 16 MFMAs): 1 = MFMAs and select work only for the 16-query column blocks that hold queries
+// (1 ... 4); 2 = at most 16 queries and D <= 1536: additionally the B fragments of that one column block are kept in LDS
+// for the whole chunk (kNarrowQVec vectors) instead of being streamed from L2 every K-step.
+constexpr int kNarrowMaxKS = 48;                            // 32-dim k-steps of the LDS-resident query block (D <= 1536)
+template <int ABL, int BS, int FP = 8, int NARROW = 0>
 __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKloopExtra ex) {
     constexpr int NWAVES = 8, RING = 2 * BS, HT = 8, CB = 4;
     constexpr int PPS = kTilesPerSpan16 / HT;               // passes per span (8)
     static_assert(PPS % FP == 0, "bins must tile the span");
     constexpr int kStageVec = HT * 2 * 64;                  // 16-byte vectors per K-step stage (16 KiB)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * kStageVec * 16];
+    constexpr int kNarrowQVec = NARROW == 2 ? kNarrowMaxKS * 64 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(RING * kStageVec + kNarrowQVec) * 16];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
+    half8 *lds_q = reinterpret_cast<half8 *>(smem + RING * kStageVec * 16);
 
     const int b = blockIdx.x;
     const int x = b & 7, j = b >> 3;
@@ -281,16 +288,38 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half8 *>(a.qpanels + (size_t)(q0 / 16) * KS * 64), 0, 0x7fffffff, 0x00020000);
     auto load_b = [&](int kk, int ks) {
+        if (NARROW == 2) {
+            bq[0][ks] = lds_q[(kk * 2 + ks) * 64 + lane];
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
             bq[cb][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
                                                        rsq, lane16, (cb * KS + (ABL == 3 ? 0 : kk * 2) + ks) * 1024, 0));
     };
+    if (NARROW == 2) {   // column block 0 of this query tile: KS contiguous 1-KiB fragments (every wave helps, wave 0 uses them)
+        const half8 *src = a.qpanels + (size_t)((int64_t)qt * (NWAVES * CB)) * KS * 64;
+        for (int i = tid; i < KS * 64; i += NWAVES * 64) lds_q[i] = src[i];
+    }
 #pragma unroll
     for (int i = 0; i < BS; ++i)
         if (i < nsteps) stage_issue(i, i);
-    load_b(0, 0);
+    // A wave whose 64 query columns are all padding (small batches: 1 ... 448 queries leave 7 ... 1 such waves in the only
+    // query tile) keeps its share of the A staging and the barriers going and nothing else: a single query then costs
+    // one wave's matrix work per workgroup instead of eight, and the scan runs at the rate the panels stream in.
+    if (a.nq_valid > 0 && q0 >= a.nq_valid) {
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            stage_issue(step + BS < nsteps ? step + BS : nsteps - 1, (step + BS) % RING);
+            if (BS == 1 || (step % BS) == BS - 1) __syncthreads();
+        }
+        return;
+    }
+    // column blocks of this wave that hold queries (wave-uniform)
+    const int ncb = !NARROW ? CB : NARROW == 2 ? 1 : __builtin_amdgcn_readfirstlane((int)((a.nq_valid - q0 + 15) / 16 < CB ? (a.nq_valid - q0 + 15) / 16 : CB));
+    if (NARROW != 2) load_b(0, 0);
     __syncthreads();
+    if (NARROW == 2) load_b(0, 0);      // (the query block in LDS is complete only behind the barrier)
 
     half8 fr[2][4];
     auto read_group = [&](int buf, int grp, half8(&dst)[4]) {   // group grp = (ks = grp>>1, tiles 4*(grp&1)..+3)
@@ -332,13 +361,24 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
                     read_group((step + 1) % RING, 0, fr[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!NARROW) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb)
+                            if (ABL != 2)
+                                acc[(grp & 1) * 4 + t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    fr[grp & 1][t], bq[cb][grp >> 1], acc[(grp & 1) * 4 + t][cb], 0, 0, 0);
+                } else {
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
-                        if (ABL != 2)
-                            acc[(grp & 1) * 4 + t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                fr[grp & 1][t], bq[cb][grp >> 1], acc[(grp & 1) * 4 + t][cb], 0, 0, 0);
+                        if (cb < ncb) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                acc[(grp & 1) * 4 + t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    fr[grp & 1][t], bq[cb][grp >> 1], acc[(grp & 1) * 4 + t][cb], 0, 0, 0);
+                        }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (grp == 1) load_b(kn, 0);
             }
@@ -354,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
             const unsigned id = (unsigned)((slice % FP) * HT + t);   // quad number inside the level-1 bin
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
+                if (NARROW && cb >= ncb) continue;       // (its minima stay +inf: nothing reads those columns)
                 const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
                                           fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
                 const float v = pack_score(qm, idmask, id);

@@ -533,7 +533,14 @@ void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStr
                 case 8: scan16_kloop_kernel<3, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
                 case 9: scan16_kloop_kernel<4, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
 #endif
-                default: scan16_kloop_kernel<0, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
+                default:
+                    if (sa.nq_valid > 0 && sa.nq_valid <= 16 && h->ksteps / 2 <= kNarrowMaxKS && !h->small_batch_off)
+                        scan16_kloop_kernel<0, 3, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
+                    else if (sa.nq_valid > 0 && sa.nq_valid < 64 && !h->small_batch_off)
+                        scan16_kloop_kernel<0, 2, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
+                    else
+                        scan16_kloop_kernel<0, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
+                    break;
             }
             VDB_HIP(hipGetLastError());
             return;
