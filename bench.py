@@ -226,6 +226,37 @@ def scaling_reference_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup)
     return leg
 
 
+def serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d):
+    """Serving-shaped batches on the headline index: wall time of one search_device + synchronise (median of 30) for
+    1 and 64 queries, and the HBM roofline of the scan -- a single query streams the whole scan copy once."""
+    leg = {}
+    for nq in (1, 64):
+        for _ in range(5):
+            index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
+        torch.cuda.synchronize()
+        index.set_option("timing", 1)
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        st = index.stats()
+        index.set_option("timing", 0)
+        i8 = int(st.get("scan_dtype", 0)) == 1
+        dpad = -(-d // 32) * 32 if i8 else -(-d // 16) * 16
+        panel_bytes = float(n) * dpad * (1 if i8 else 2)
+        scan_ms = float(st["last_scan_ms"])
+        leg[f"nq{nq}"] = {"latency_us": round(float(np.median(ts)) * 1e6, 1), "scan_us": round(scan_ms * 1e3, 1),
+                          "roofline": {"bound": "hbm", "achieved": round(panel_bytes / (scan_ms * 1e-3) / 1e9, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(panel_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "algorithmic_bytes_per_launch": panel_bytes,
+                                       "note": "rows x padded dims x %d B: the %s scan copy read once" %
+                                               (1 if i8 else 2, "int8" if i8 else "fp16")}}
+    return leg
+
+
 def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
     """MFMA roofline of the dominant kernel from the HIP-event time the library recorded on the search stream."""
     scan_ms = float(st["last_scan_ms"])
@@ -537,6 +568,7 @@ def main() -> int:
                 "ids_equal_cpu_oracle_first32": bool(np.array_equal(I_t[:32].cpu().numpy(), io_))}}
             gi.close()
             del Xg, Qg
+            out["also"]["serving"] = serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d)
             index.close()
             out["also"]["marco12.5m"] = scaling_reference_leg(vdbhip, torch, dev, local_rank, stream,
                                                               min(args.steps, 10), min(args.warmup, 2))

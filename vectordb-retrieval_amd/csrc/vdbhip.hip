@@ -945,6 +945,7 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         v8 &= 7;
 #endif
         if (Qpad % 1024 != 0) v8 &= 1;
+        if ((int64_t)g.nchunks * (Qpad / 1024) < 256) v8 &= 1;     // too few 1024-query tiles to cover the chip: 512-query tiles
         if (nw_small < 8) v8 = 8 + nw_small;
         const int qtile = (v8 > 8) ? 64 * nw_small : (v8 >= 2) ? 1024 : 512;
         s8.nqtiles = (int)((v8 > 8 ? nq + qtile - 1 : Qpad) / qtile);
