@@ -77,6 +77,7 @@ typedef struct vdb_stats_s {
     int32_t has_i8_copy;       /* 1 if the index holds the int8 scan copy (byte-valued integer corpus, D <= 128) */
     int64_t last_rows_scanned; /* IVF: (query, row) pairs scanned by the last search (rows of the probed lists) */
     int64_t upload_blocks;     /* row blocks the last vdb_add / vdb_ivf_add streamed through the pinned staging buffers */
+    int64_t graph_replays;     /* searches served by launching the captured hipGraph (option "graph") since the handle was made */
 } vdb_stats_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -169,7 +170,10 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * (staging block of the row-block ingestion, default 64), "ivf_part" (0 auto: spans of 512 rows per row part of the IVF list scan -- long lists are
  * cut into parts scanned by one workgroup each), "ivf_st" (0 auto, 2 / 4 / 8 tiles per LDS stage of the int8 list scan),
  * "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
- * scan), "small_batch" (1 default: batches of <= 512 queries are
+ * scan), "graph" (default 0; 1: a vdb_search_device / vdb_search_partial_device / vdb_ivf_search*_device call
+ * of at most 4096 queries on a non-null stream that repeats with the same buffers, shape and stream -- a serving loop --
+ * is captured into a hipGraph on its second occurrence and replayed afterwards; any vdb_set_option / add / train drops the
+ * graph; the caller keeps the buffers alive and rewrites the queries in place), "small_batch" (1 default: batches of <= 512 queries are
  * scanned with finer row chunks and, up to 256 queries, 1 / 2 / 4-wave workgroups so that the grid still covers the
  * chip; 0: the batch-shaped grid for every batch size).
  * "scan_variant" and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped

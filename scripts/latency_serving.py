@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nq", type=int, default=0)
 ap.add_argument("--kind", default="sift", help="sift | gaussian (1M x 128, l2) | marco (2M x 768, ip, rows generated on device)")
 ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--graph", type=int, default=0, help="1: option graph (hipGraph replay of the repeated search)")
 ap.add_argument("--ivf", type=int, default=0, help="IVF-Flat nlist = 1024 with this nprobe instead of the flat index")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -39,7 +40,9 @@ elif a.ivf:
 else:
     idx = vdbhip.FlatIndex(128, "l2", 0)
     idx.add(X)
-stream = torch.cuda.current_stream().cuda_stream
+side = torch.cuda.Stream()          # (a non-null stream: the legacy default stream cannot be captured)
+stream = side.cuda_stream
+idx.set_option("graph", a.graph)
 q_t = torch.from_numpy(Q).to(dev)
 for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):
     D_t = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
@@ -53,5 +56,5 @@ for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):
         ts.append(time.perf_counter() - t0)
     st = idx.stats()
     print(json.dumps({"kind": a.kind, "ivf_nprobe": a.ivf, "nq": nq, "k": a.k, "median_us": round(float(np.median(ts[10:])) * 1e6, 1),
-                      "min_us": round(min(ts[10:]) * 1e6, 1), "path": st["last_path_name"],
+                      "min_us": round(min(ts[10:]) * 1e6, 1), "graph_replays": st.get("graph_replays", 0), "path": st["last_path_name"],
                       "scan_dtype": int(st.get("scan_dtype", 0))}), flush=True)

@@ -621,3 +621,56 @@ def test_small_batches_on_the_kloop_scan_stay_exact(vdb, oracle, d, metric):
             np.testing.assert_array_equal(I, Io[:nq], err_msg=f"nq={nq} small_batch={sb}")
             np.testing.assert_array_equal(D, Do[:nq], err_msg=f"nq={nq} small_batch={sb}")
     idx.close()
+
+
+def test_graph_replay_of_a_serving_loop_is_exact(vdb, oracle):
+    """Option `graph`: a device-resident search repeated with the same buffers, shape and stream is captured into a
+    hipGraph on its second call and replayed from the third.  The queries are rewritten IN PLACE between calls: every
+    replay returns the oracle's bits for the queries of that call; a change of shape or options drops the graph."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((90_000, 96)).astype(np.float32)
+    Q = rng.standard_normal((6 * 24, 96)).astype(np.float32)
+    Do, Io = oracle.knn(X, Q, 10, "l2")
+    dev = torch.device("cuda", 0)
+    idx = vdb.FlatIndex(96, "l2", 0)
+    idx.add(X)
+    idx.set_option("graph", 1)
+    side = torch.cuda.Stream()
+    q_t = torch.empty((24, 96), dtype=torch.float32, device=dev)
+    D_t = torch.empty((24, 10), dtype=torch.float32, device=dev)
+    I_t = torch.empty((24, 10), dtype=torch.int64, device=dev)
+    for call in range(6):
+        with torch.cuda.stream(side):
+            q_t.copy_(torch.from_numpy(Q[24 * call:24 * call + 24]), non_blocking=False)
+        idx.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        np.testing.assert_array_equal(I_t.cpu().numpy(), Io[24 * call:24 * call + 24], err_msg=f"call {call}")
+        np.testing.assert_array_equal(D_t.cpu().numpy(), Do[24 * call:24 * call + 24], err_msg=f"call {call}")
+    st = idx.stats()
+    assert st["graph_replays"] == 5, st                    # call 0 eager, call 1 captured + launched, 2..5 replayed
+    idx.search_device(q_t.data_ptr(), 7, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)   # other shape: eager again
+    side.synchronize()
+    np.testing.assert_array_equal(I_t.cpu().numpy()[:7], Io[120:127])
+    assert idx.stats()["graph_replays"] == 5
+    idx.set_option("graph", 0)
+    idx.close()
+
+    # IVF: 18 dispatches per search in one graph
+    C = X[rng.choice(len(X), 64, replace=False)].copy()
+    ivf = vdb.IVFFlatIndex(96, 64, "l2", 0)
+    ivf.set_centroids(C)
+    ivf.add(X)
+    ivf.set_nprobe(6)
+    ivf.set_option("graph", 1)
+    Dv, Iv = oracle.ivf_search(X, C, ivf.assignment(), Q, 10, 6, "l2")
+    for call in range(5):
+        with torch.cuda.stream(side):
+            q_t.copy_(torch.from_numpy(Q[24 * call:24 * call + 24]))
+        ivf.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        np.testing.assert_array_equal(I_t.cpu().numpy(), Iv[24 * call:24 * call + 24], err_msg=f"ivf call {call}")
+        np.testing.assert_array_equal(D_t.cpu().numpy(), Dv[24 * call:24 * call + 24], err_msg=f"ivf call {call}")
+    assert ivf.stats()["graph_replays"] == 4
+    ivf.close()

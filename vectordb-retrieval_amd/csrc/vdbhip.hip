@@ -105,6 +105,20 @@ struct vdb_index_s {
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    // option "graph": a device-resident search that repeats with the same shape and buffers (a serving loop) is captured
+    // into a hipGraph on its second call and replayed from the third (graph_or_run)
+    int graph_mode = 0;
+    struct GraphKey {
+        const void *q = nullptr, *o1 = nullptr, *o2 = nullptr;
+        int64_t nq = 0;
+        int k = 0, kind = 0, nprobe = 0;
+        hipStream_t st = nullptr;
+        bool operator==(const GraphKey &o) const {
+            return q == o.q && o1 == o.o1 && o2 == o.o2 && nq == o.nq && k == o.k && kind == o.kind && nprobe == o.nprobe && st == o.st;
+        }
+    } graph_key, graph_warm;
+    hipGraphExec_t graph_exec = nullptr;
+    int64_t graph_replays = 0;
     int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 512 queries keep the batch-shaped grid
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
     // host copies of the corpus statistics
@@ -326,9 +340,12 @@ void build_rows_i8(vdb_index_s *h, hipStream_t st) {
         h->x32.as<float>(), h->N, h->dim, h->D4, h->rows8_pitch, h->i8_cx, h->rows8.as<signed char>());
 }
 
+void graph_reset(vdb_index_s *h);
+
 void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base,
                  hipStream_t st) {
     if (n < 0) throw Error(VDB_ERR_INVALID, "negative row count");
+    graph_reset(h);
     if (n > 2147483647ll - 1024) throw Error(VDB_ERR_UNSUPPORTED, "more than 2^31 rows per shard");
     const int D = h->dim, D4 = h->D4;
     h->built = false;
@@ -1078,6 +1095,63 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
     h->last.last_path = VDB_PATH_MFMA_SCAN;
 }
 
+// ---- hipGraph replay of a repeated device-resident search -----------------------------------------------------------
+// A small batch is a chain of ~9 (flat) / ~18 (IVF) short dependent dispatches.  With option "graph" = 1 the first call
+// of a (buffers, shape, stream) combination runs eagerly (it sizes the workspace: allocation is illegal while capturing),
+// the second is captured into a graph and launched, later ones replay the graph.  Anything that changes the index or an
+// option drops the graph (graph_reset).
+void graph_reset(vdb_index_s *h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    h->graph_key = vdb_index_s::GraphKey{};
+    h->graph_warm = vdb_index_s::GraphKey{};
+}
+
+constexpr int64_t kGraphMaxQueries = 4096;
+
+template <class F>
+void graph_or_run(vdb_index_s *h, const vdb_index_s::GraphKey &key, F &&run) {
+    const bool eligible = h->graph_mode && key.st != nullptr && !h->timing && key.nq > 0 && key.nq <= kGraphMaxQueries;
+    if (!eligible) {
+        run();
+        return;
+    }
+    if (h->graph_exec && key == h->graph_key) {
+        VDB_HIP(hipGraphLaunch(h->graph_exec, key.st));
+        ++h->graph_replays;
+        return;
+    }
+    if (!(key == h->graph_warm)) {
+        run();
+        h->graph_warm = key;
+        return;
+    }
+    const vdb_index_s::GraphKey warm = h->graph_warm;
+    graph_reset(h);
+    VDB_HIP(hipStreamBeginCapture(key.st, hipStreamCaptureModeThreadLocal));
+    hipGraph_t g = nullptr;
+    bool captured = true;
+    try {
+        run();
+    } catch (...) {
+        captured = false;
+    }
+    const hipError_t e_end = hipStreamEndCapture(key.st, &g);
+    hipGraphExec_t ex = nullptr;
+    if (captured && e_end == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(g);
+        h->graph_exec = ex;
+        h->graph_key = key;
+        h->graph_warm = warm;
+        VDB_HIP(hipGraphLaunch(ex, key.st));
+        ++h->graph_replays;
+        return;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    run();          // the capture did not work out (e.g. a workspace had to grow): this call runs eagerly, the next one warms up again
+}
+
 void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, int64_t *I, double *pk,
                         int64_t *pi, hipStream_t st) {
     if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
@@ -1202,6 +1276,7 @@ int vdb_destroy(vdb_handle h) {
                          &h->ivf_cnt, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
         for (auto b : all) b->release();
+        graph_reset(h);
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
         for (int i = 0; i < 2; ++i) {
@@ -1263,7 +1338,9 @@ int vdb_search_device(vdb_handle hh, const float *q_dev, int64_t nq, int k, floa
         auto *h = check(hh);
         if (nq > 0 && (!D_dev || !I_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
         set_device(h->device);
-        search_device_impl(h, q_dev, nq, k, D_dev, I_dev, nullptr, nullptr, as_stream(stream));
+        vdb_index_s::GraphKey key;
+        key.q = q_dev; key.o1 = D_dev; key.o2 = I_dev; key.nq = nq; key.k = k; key.kind = 1; key.st = as_stream(stream);
+        graph_or_run(h, key, [&] { search_device_impl(h, q_dev, nq, k, D_dev, I_dev, nullptr, nullptr, as_stream(stream)); });
     });
 }
 
@@ -1273,7 +1350,9 @@ int vdb_search_partial_device(vdb_handle hh, const float *q_dev, int64_t nq, int
         auto *h = check(hh);
         if (nq > 0 && (!keys_dev || !ids_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
         set_device(h->device);
-        search_device_impl(h, q_dev, nq, k, nullptr, nullptr, keys_dev, ids_dev, as_stream(stream));
+        vdb_index_s::GraphKey key;
+        key.q = q_dev; key.o1 = keys_dev; key.o2 = ids_dev; key.nq = nq; key.k = k; key.kind = 2; key.st = as_stream(stream);
+        graph_or_run(h, key, [&] { search_device_impl(h, q_dev, nq, k, nullptr, nullptr, keys_dev, ids_dev, as_stream(stream)); });
     });
 }
 
@@ -1406,6 +1485,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
                                      h->panels8.cap + h->bias8.cap + h->rows8.cap + h->rowstat8.cap + h->ws.bytes());
         s.has_i8_copy = h->i8_ok ? 1 : 0;
         s.upload_blocks = h->last_upload_blocks;
+        s.graph_replays = h->graph_replays;
         s.last_rows_scanned = 0;
         if (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma && h->ivf_plan.p) {   // (of the last batch of the call)
             IvfPlan pl;
@@ -1480,7 +1560,11 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         auto *h = check(hh);
         if (!key) throw Error(VDB_ERR_INVALID, "null option name");
         const std::string k(key);
-        if (k == "force_path") {
+        graph_reset(h);                        // (a captured search embodies the options it was captured under)
+        if (k == "graph") {
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "graph must be 0 or 1");
+            h->graph_mode = (int)value;
+        } else if (k == "force_path") {
             if (value != 0 && value != 1 && value != 2 && value != 3)
                 throw Error(VDB_ERR_INVALID, "force_path must be 0, 1, 2 or 3");
             h->force_path = (int)value;

@@ -32,6 +32,7 @@ class Stats(Structure):
         ("last_scan_ms", c_float), ("last_total_ms", c_float), ("nlist", c_int32), ("nprobe", c_int32),
         ("scan_dtype", c_int32), ("has_i8_copy", c_int32), ("last_rows_scanned", c_int64),
         ("upload_blocks", c_int64),
+        ("graph_replays", c_int64),
     ]
 
     def as_dict(self):
