@@ -247,11 +247,19 @@ def serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d):
         dpad = -(-d // 32) * 32 if i8 else -(-d // 16) * 16
         panel_bytes = float(n) * dpad * (1 if i8 else 2)
         scan_ms = float(st["last_scan_ms"])
+        traffic, source = None, None
+        try:
+            ent = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("sift1m_serving_nq1", {})
+            if i8 and n == 1_000_000 and d == 128:
+                traffic, source = ent.get("hbm_bytes_per_launch"), ent.get("source")
+        except Exception:  # noqa: BLE001
+            pass
         leg[f"nq{nq}"] = {"latency_us": round(float(np.median(ts)) * 1e6, 1), "scan_us": round(scan_ms * 1e3, 1),
                           "roofline": {"bound": "hbm", "achieved": round(panel_bytes / (scan_ms * 1e-3) / 1e9, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(panel_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "algorithmic_bytes_per_launch": panel_bytes,
+                                       "algorithmic_bytes_per_launch": panel_bytes, "traffic": traffic,
+                                       "traffic_source": (source + " -- a recorded PMC pass, not measured in this run") if source else None,
                                        "note": "rows x padded dims x %d B: the %s scan copy read once" %
                                                (1 if i8 else 2, "int8" if i8 else "fp16")}}
     return leg
