@@ -168,8 +168,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  * shapes of the int8 scan), "i8_group" (8 or 4 rows per select group of the flat int8 scan), "ivf_nw" (0 auto, 2 / 4 / 8
  * waves per IVF work item), "ivf_bt" (0 auto, 4 / 16 tiles per IVF bin), "select_variant" (0..2), "upload_block_mb"
  * (staging block of the row-block ingestion, default 64), "ivf_part" (0 auto: spans of 512 rows per row part of the IVF list scan -- long lists are
- * cut into parts scanned by one workgroup each), "ivf_st" (0 auto, 2 / 4 / 8 tiles per LDS stage of the int8 list scan),
- * "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
+ * cut into parts scanned by one workgroup each), "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
  * scan), "graph" (default 0; 1: a vdb_search_device / vdb_search_partial_device / vdb_ivf_search*_device call
  * of at most 4096 queries on a non-null stream that repeats with the same buffers, shape and stream -- a serving loop --
  * is captured into a hipGraph on its second occurrence and replayed afterwards; any vdb_set_option / add / train drops the

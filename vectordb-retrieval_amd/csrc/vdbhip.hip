@@ -100,7 +100,6 @@ struct vdb_index_s {
     int rows8_pitch = 0;
     bool i8_ok = false;
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
-    int ivf_st = 0;                          // option "ivf_st": tiles per LDS stage of the int8 IVF scan (0 auto, 2 / 4 / 8)
     int ivf_part = 0;                        // option "ivf_part": spans per row part of the IVF list scan (0 auto)
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
@@ -1583,9 +1582,6 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_bt") {
             if (value != 0 && value != 4 && value != 16) throw Error(VDB_ERR_INVALID, "ivf_bt must be 0, 4 or 16");
             h->ivf_bt = (int)value;
-        } else if (k == "ivf_st") {
-            if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_st must be 0, 2, 4 or 8");
-            h->ivf_st = (int)value;
         } else if (k == "ivf_part") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "ivf_part must be 0 (auto) or 1..1024 spans");
             h->ivf_part = (int)value;
