@@ -157,26 +157,36 @@ int vdb_ivf_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, 
 
 /* ---- introspection / tuning ---------------------------------------------------------------- */
 int vdb_stats(vdb_handle h, vdb_stats_t *out);
-/* options: "force_path" (0 auto, 1 exact kernels only, 2 MFMA scan whenever legal, 3 exact kernels in their
- * one-query-per-wave form), "timing" (1: (re)start
- * recording HIP-event times of every search, averaged by vdb_stats), "list_cap" (work-list capacity per query),
- * tuning knobs used by scripts/: "scan_variant", "select_variant", "spans_per_chunk", "kloop_qgroup", and
- * "panel_layout" (0 auto: 16-row-tile panels for D > 128; 1: 32-row tiles for every D; 2: 16-row tiles for every D;
- * takes effect at the next vdb_add), "panel_dtype" (0 auto: byte-valued integer corpora are ALSO kept as an int8 scan
- * copy and integer query batches in the byte window are scanned with int8 MFMA; 1: fp16 scan only).
- * Tuning knobs whose every setting returns exact results (scripts/sweep_*.py): "i8_variant" (0..5: tile / stage / wave
- * shapes of the int8 scan), "i8_group" (8 or 4 rows per select group of the flat int8 scan), "ivf_nw" (0 auto, 2 / 4 / 8
- * waves per IVF work item), "ivf_bt" (0 auto, 4 / 16 tiles per IVF bin), "select_variant" (0..2), "upload_block_mb"
- * (staging block of the row-block ingestion, default 64), "ivf_part" (0 auto: spans of 512 rows per row part of the IVF list scan -- long lists are
- * cut into parts scanned by one workgroup each), "ivf_min_batch" (default 1: smallest query batch the list-major MFMA scan serves; smaller ones take the exact list
- * scan), "graph" (default 0; 1: a vdb_search_device / vdb_search_partial_device / vdb_ivf_search*_device call
- * of at most 4096 queries on a non-null stream that repeats with the same buffers, shape and stream -- a serving loop --
- * is captured into a hipGraph on its second occurrence and replayed afterwards; any vdb_set_option / add / train drops the
- * graph; the caller keeps the buffers alive and rewrites the queries in place), "small_batch" (1 default: batches of <= 512 queries are
- * scanned with finer row chunks and, up to 256 queries, 1 / 2 / 4-wave workgroups so that the grid still covers the
- * chip; 0: the batch-shaped grid for every batch size).
- * "scan_variant" and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`); the shipped
- * library rejects them. */
+/* Options (vdb_set_option; every setting returns exact results unless it says otherwise):
+ *   behaviour
+ *     "force_path"      0 auto | 1 exact kernels only | 2 MFMA scan whenever legal | 3 exact kernels, one query per wave
+ *     "timing"          1: (re)start recording HIP-event times of every search on its stream, averaged by vdb_stats
+ *     "list_cap"        work-list capacity per query (0 = default max(64, 2k + 32))
+ *     "panel_layout"    0 auto (16-row-tile panels for D > 128) | 1 32-row tiles for every D | 2 16-row tiles for every D;
+ *                       takes effect at the next vdb_add
+ *     "panel_dtype"     0 auto: byte-valued integer corpora are ALSO kept as an int8 scan copy, and integer query batches
+ *                       in the byte window are scanned with int8 MFMA | 1 fp16 scan only
+ *     "upload_block_mb" staging block of the row-block ingestion (default 64)
+ *     "small_batch"     1 (default): batches of <= 512 queries are scanned with finer row chunks and, up to 256 queries,
+ *                       1 / 2 / 4-wave workgroups, so that the grid still covers the chip; D > 128: waves without queries
+ *                       only stage panels, <= 16 queries keep their query block in LDS | 0 the batch shape for every size
+ *     "ivf_min_batch"   smallest query batch the list-major MFMA scan of the IVF index serves (default 1); smaller ones
+ *                       take the exact per-query list scan
+ *     "graph"           0 (default) | 1: a vdb_search_device / vdb_search_partial_device / vdb_ivf_search*_device call of
+ *                       at most 4096 queries on a non-null stream that repeats with the same buffers, shape and stream
+ *                       (a serving loop) is captured into a hipGraph on its second occurrence and replayed afterwards;
+ *                       any vdb_set_option / add / train drops the graph; the caller keeps the buffers alive and
+ *                       rewrites the queries in place
+ *   tuning knobs (scripts/sweep_*.py)
+ *     "i8_variant"      0..5: tile / stage / wave shapes of the flat int8 scan
+ *     "i8_group"        8 (default) | 4 rows per select group of the flat int8 scan
+ *     "ivf_nw"          0 auto | 2 / 4 / 8 waves per IVF work item
+ *     "ivf_bt"          0 auto | 4 / 16 tiles per IVF bin
+ *     "ivf_part"        0 auto | spans (512 rows) per row part of the IVF list scan: long lists are cut into parts
+ *                       scanned by one workgroup each
+ *     "select_variant"  0..2;  "spans_per_chunk", "kloop_qgroup": grid shaping of the flat scans
+ *     "scan_variant"    and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`, WRONG
+ *                       results by design); the shipped library rejects them. */
 int vdb_set_option(vdb_handle h, const char *key, double value);
 
 /* ---- test hooks (used by tests/ to validate the error bound of the fp16 scan) -------------- */
