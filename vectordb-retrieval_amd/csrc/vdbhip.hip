@@ -661,8 +661,8 @@ void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, 
         g = scan_geometry(h, k, nq);
         if (!g.ok) direct_rows = scan_geometry_direct(h, k, g);
     }
-    // (measured on 1M x 128: the MFMA pipeline answers 1..512 queries in ~0.3 ms, the exhaustive float64 kernel
-    //  needs ~0.07 ms per query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
+    // (measured on 1M x 128 with host I/O: the MFMA pipeline answers 1..512 queries in 0.13..0.18 ms, the exhaustive float64
+    //  kernel needs 0.3 ms for one query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
     // Between the dense small-corpus path (<= 8192 rows) and 32768 rows the scan pays off once the batch carries
     // enough (query, row) pairs: ~0.3 ms of fixed pipeline cost against ~7e-8 ms per pair in the exhaustive kernel.
     use_scan = use_scan && g.ok &&
