@@ -654,6 +654,21 @@ def test_graph_replay_of_a_serving_loop_is_exact(vdb, oracle):
     side.synchronize()
     np.testing.assert_array_equal(I_t.cpu().numpy()[:7], Io[120:127])
     assert idx.stats()["graph_replays"] == 5
+    # a larger batch grows the workspace: the buffers the graph was captured with are gone, so the old graph must not be
+    # replayed when its shape comes back (it is re-captured instead)
+    qb_t = torch.from_numpy(Q).to(dev)
+    Db_t = torch.empty((len(Q), 10), dtype=torch.float32, device=dev)
+    Ib_t = torch.empty((len(Q), 10), dtype=torch.int64, device=dev)
+    idx.search_device(qb_t.data_ptr(), len(Q), 10, Db_t.data_ptr(), Ib_t.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    np.testing.assert_array_equal(Ib_t.cpu().numpy(), Io)
+    for call in range(3):
+        with torch.cuda.stream(side):
+            q_t.copy_(torch.from_numpy(Q[24 * call:24 * call + 24]))
+        idx.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        np.testing.assert_array_equal(I_t.cpu().numpy(), Io[24 * call:24 * call + 24], err_msg=f"after growth, call {call}")
+    assert idx.stats()["graph_replays"] == 7                # eager, captured + launched, replayed
     idx.set_option("graph", 0)
     idx.close()
 

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,12 +26,17 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// bumped by every (re)allocation or release of a DevBuf: a captured hipGraph holds raw buffer addresses, so it may only be
+// replayed while no buffer of this process has moved since its capture (graph_or_run)
+std::atomic<uint64_t> g_alloc_epoch{0};
+
 // growable device buffer
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
+        g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
         if (p) VDB_HIP(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -40,7 +46,10 @@ struct DevBuf {
         cap = want;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+            (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
@@ -117,6 +126,7 @@ struct vdb_index_s {
         }
     } graph_key, graph_warm;
     hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_epoch = 0;                // g_alloc_epoch when the graph was captured
     int64_t graph_replays = 0;
     int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 512 queries keep the batch-shaped grid
     int i8_cx = 0, i8_ks = 0, i8_disable = 0, i8_variant = 3;   // (variant 3: +2 % over 0 on the bench shape, scripts/sweep_i8.py)
@@ -1115,10 +1125,15 @@ void graph_or_run(vdb_index_s *h, const vdb_index_s::GraphKey &key, F &&run) {
         run();
         return;
     }
-    if (h->graph_exec && key == h->graph_key) {
+    if (h->graph_exec && key == h->graph_key && h->graph_epoch == g_alloc_epoch.load(std::memory_order_relaxed)) {
         VDB_HIP(hipGraphLaunch(h->graph_exec, key.st));
         ++h->graph_replays;
         return;
+    }
+    if (h->graph_exec) {      // another shape, or a buffer moved since the capture (the graph holds raw addresses): drop it
+        (void)hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+        h->graph_key = vdb_index_s::GraphKey{};
     }
     if (!(key == h->graph_warm)) {
         run();
@@ -1142,6 +1157,7 @@ void graph_or_run(vdb_index_s *h, const vdb_index_s::GraphKey &key, F &&run) {
         h->graph_exec = ex;
         h->graph_key = key;
         h->graph_warm = warm;
+        h->graph_epoch = g_alloc_epoch.load(std::memory_order_relaxed);
         VDB_HIP(hipGraphLaunch(ex, key.st));
         ++h->graph_replays;
         return;
