@@ -414,7 +414,8 @@ def main() -> int:
         extras["plugin_host_io_ms"] = round(med * 1e3, 4)
         extras["plugin_host_io_note"] = ("HipExactSearch.batch_search(Q (10000,128) pageable numpy) -> numpy (D, I): H2D of Q "
                                          "and D2H of the result inside the timed call; median of 11 after 3 warm-ups; "
-                                         "first_call_ms = the very first call after build_index, no warm-up")
+                                         "first_call_ms = the very first call after build_index, no warm-up search "
+                                         "(build_index sizes the workspace for 10 000 queries: vdb_reserve)")
         index = algo.index
     else:
         index = vdbhip.FlatIndex(d, metric, local_rank)

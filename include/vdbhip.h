@@ -155,6 +155,13 @@ int vdb_ivf_search_device(vdb_handle h, const float *q_dev, int64_t nq, int k, f
 int vdb_ivf_search_partial_device(vdb_handle h, const float *q_dev, int64_t nq, int k, double *keys_dev,
                                   int64_t *ids_dev, void *stream);
 
+/* Sizes the search workspace for batches of up to nq queries and top-k NOW instead of inside the first search (works on
+ * flat and IVF handles after add): one untimed search whose queries are corpus rows.  The reference times its very first
+ * batch_search, allocations included (experiment_runner.py:431-437; metrics_methodology.md:119-121: no warm-up) -- the
+ * plugins call this from build_index (`reserve_queries`, default 10 000), as FAISS' GPU resources reserve their scratch
+ * memory at construction. */
+int vdb_reserve(vdb_handle h, int64_t nq, int k);
+
 /* ---- introspection / tuning ---------------------------------------------------------------- */
 int vdb_stats(vdb_handle h, vdb_stats_t *out);
 /* Options (vdb_set_option; every setting returns exact results unless it says otherwise):

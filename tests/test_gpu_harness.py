@@ -146,3 +146,31 @@ def test_row_block_ingestion_from_a_memmap_larger_than_the_staging_buffer(vdb, o
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     ivf.close()
+
+
+def test_build_index_reserves_the_workspace_of_the_first_batch(vdb, oracle):
+    """The reference times its very first batch_search (experiment_runner.py:431-437): `build_index` sizes the search
+    workspace for `reserve_queries` queries (default 10 000) so that the first call allocates nothing; results as ever."""
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((60_000, 64)).astype(np.float32)
+    Q = rng.standard_normal((3000, 64)).astype(np.float32)
+    algo = vdb.get_algorithm_instance("HipExactSearch", 64, name="r", metric="l2")
+    algo.build_index(X)
+    before = algo.index.stats()["bytes_resident"]
+    D, I = algo.batch_search(Q, k=10)
+    assert algo.index.stats()["bytes_resident"] == before         # nothing grew during the first search
+    Do, Io = oracle.knn(X, Q[:64], 10, "l2")
+    np.testing.assert_array_equal(I[:64], Io)
+    lazy = vdb.get_algorithm_instance("HipExactSearch", 64, name="r0", metric="l2", reserve_queries=0)
+    lazy.build_index(X)
+    small = lazy.index.stats()["bytes_resident"]
+    assert small < before
+    D2, I2 = lazy.batch_search(Q, k=10)
+    np.testing.assert_array_equal(I2, I)
+    np.testing.assert_array_equal(D2, D)
+    assert lazy.index.stats()["bytes_resident"] > small
+    ivf = vdb.get_algorithm_instance("HipApproximateSearch", 64, name="a", index_type="IVF64,Flat", metric="l2", nprobe=8)
+    ivf.build_index(X)
+    b0 = ivf.index.stats()["bytes_resident"]
+    ivf.batch_search(Q, k=10)
+    assert ivf.index.stats()["bytes_resident"] == b0

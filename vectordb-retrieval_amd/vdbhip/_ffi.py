@@ -69,6 +69,7 @@ SIGNATURES = {
     "vdb_ivf_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "vdb_ivf_search_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "vdb_ivf_search_partial_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vdb_reserve": (c_int, [c_void_p, c_int64, c_int]),
     "vdb_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "vdb_set_option": (c_int, [c_void_p, c_char_p, c_double]),
     "vdb_debug_fetch_stamps": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int64)]),

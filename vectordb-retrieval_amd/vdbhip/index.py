@@ -100,6 +100,11 @@ class FlatIndex:
         _ffi.check(self._lib.vdb_stats(self._handle(), ctypes.byref(s)))
         return s.as_dict()
 
+    def reserve(self, nq: int, k: int = 10) -> None:
+        """Size the search workspace for batches of up to `nq` queries now (vdb_reserve): the reference harness times its
+        very first batch_search, allocations included (experiment_runner.py:431-437)."""
+        _ffi.check(self._lib.vdb_reserve(self._handle(), int(nq), int(k)), build_time=True)
+
     def set_option(self, key: str, value: float) -> None:
         _ffi.check(self._lib.vdb_set_option(self._handle(), key.encode(), float(value)), build_time=True)
 

@@ -21,7 +21,7 @@ from typing import Any, Optional, Tuple
 import numpy as np
 
 from . import _ffi
-from .algorithms import _resolve_device, _safe_normalize
+from .algorithms import _resolve_device, _safe_normalize, reserve_workspace
 from .plugin_api import (BaseAlgorithm, BaseIndexer, BaseSearcher, IndexArtifact, Metadata, SearchResult,
                          register_algorithm, register_indexer, register_searcher)
 
@@ -129,6 +129,10 @@ class IVFFlatIndex:
         _ffi.check(self._lib.vdb_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
 
+    def reserve(self, nq: int, k: int = 10) -> None:
+        """Size the search workspace for batches of up to `nq` queries now (vdb_reserve)."""
+        _ffi.check(self._lib.vdb_reserve(self._h, int(nq), int(k)), build_time=True)
+
     def set_option(self, key: str, value: float) -> None:
         _ffi.check(self._lib.vdb_set_option(self._h, key.encode(), float(value)), build_time=True)
 
@@ -160,6 +164,7 @@ class HipApproximateSearch(BaseAlgorithm):
         self.index_built = True
         if "nprobe" in self.config:
             self.index.set_nprobe(int(self.config["nprobe"]))
+        reserve_workspace(self.index, self.config)
 
     def search(self, query: np.ndarray, k: int = 10) -> SearchResult:
         if not self.index_built:
@@ -286,6 +291,7 @@ class HipIVFIndexer(BaseIndexer):
         if "nprobe" in self.params:                       # runtime attribute of the index (modular.py:269-275)
             index.set_nprobe(int(self.params["nprobe"]))
             meta["nprobe"] = self.params["nprobe"]
+        reserve_workspace(index, self.params)
         return IndexArtifact(kind="hip_ivf", data=index, metadata=meta)
 
 
