@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nq", type=int, default=0)
 ap.add_argument("--kind", default="sift", help="sift | gaussian (1M x 128, l2) | marco (2M x 768, ip, rows generated on device)")
 ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--option", default="", help="name=value[,name=value] options set on the index")
 ap.add_argument("--graph", type=int, default=0, help="1: option graph (hipGraph replay of the repeated search)")
 ap.add_argument("--ivf", type=int, default=0, help="IVF-Flat nlist = 1024 with this nprobe instead of the flat index")
 a = ap.parse_args()
@@ -43,6 +44,8 @@ else:
 side = torch.cuda.Stream()          # (a non-null stream: the legacy default stream cannot be captured)
 stream = side.cuda_stream
 idx.set_option("graph", a.graph)
+for kv in filter(None, a.option.split(",")):
+    idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 q_t = torch.from_numpy(Q).to(dev)
 for nq in ([a.nq] if a.nq else [1, 8, 64, 512]):
     D_t = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
