@@ -572,7 +572,7 @@ def test_more_queries_than_one_pass_statistics_accumulate(vdb, oracle, kind):
 @pytest.mark.parametrize("kind,d,metric", [("sift", 128, "l2"), ("gauss", 128, "l2"), ("glove", 50, "ip"), ("sift", 64, "ip")])
 def test_small_batches_use_narrow_workgroups_and_stay_exact(vdb, oracle, kind, d, metric):
     """Serving-shaped batches: up to 512 queries the scan takes finer row chunks, up to 256 queries 1 / 2 / 4-wave
-    workgroups (vdbhip.hip search_batch).  Every batch size on both sides of each threshold returns the oracle's bits,
+    workgroups (search_flat.inc search_batch).  Every batch size on both sides of each threshold returns the oracle's bits,
     the same as the batch-shaped grid (`small_batch` = 0), for the int8 and the fp16 scan and both panel depths."""
     X, Q = _make(150_000, d, 2100, kind, 77)
     idx = vdb.FlatIndex(d, metric, 0)

@@ -418,803 +418,7 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     h->built = true;
 }
 
-// ---- geometry of the scan for a given (N, k) --------------------------------------------------------
-struct ScanGeom {
-    bool ok = false;
-    int64_t nspans = 0;
-    int spc = 0, rem = 0, nchunks = 0, vpl = 0;
-};
-
-// nq: queries of the batch.  Small batches (serving-shaped: up to one 512-query tile) take FINER chunks, so that the
-// grid still covers the chip: at 8192 rows per chunk a 1M-row corpus gives 128 workgroups per query tile, half the CUs.
-ScanGeom scan_geometry(const vdb_index_s *h, int k, int64_t nq) {
-    ScanGeom g;
-    const int G = h->tile16 ? 4 : 2;                        // bins (lane groups) per span
-    g.nspans = h->Npad / (G * kBinRows);
-    if (g.nspans * G < 16) return g;
-    // superbins (G per chunk) must comfortably outnumber k and fit 16 values per lane in the select
-    int64_t spc_hi = g.nspans * G / (4 * (int64_t)k);       // nsb >= 4k
-    int64_t spc_lo = (g.nspans * G + 1023) / 1024;          // nsb <= 1024
-    if (spc_hi < 1 || spc_hi < spc_lo) return g;
-    int64_t spc_want = 32 / G;                              // 8192 rows per chunk
-    // (one query tile only: from 1024 queries on the batch shape is as fast or faster -- scripts/throughput_vs_batch.py)
-    if (nq <= 512 && !h->small_batch_off) spc_want = std::max<int64_t>(1, std::min<int64_t>(spc_want, g.nspans / 512));
-    int64_t spc = std::min<int64_t>(h->spc_override > 0 ? h->spc_override : spc_want, spc_hi);
-    spc = std::max<int64_t>(spc, spc_lo);
-    if (spc < 2 && g.nspans * G >= 128) spc = std::min<int64_t>(2, spc_hi);
-    int64_t nchunks = (g.nspans + spc - 1) / spc;
-    // deal the spans evenly over a multiple of 8 chunks (one XCD label each, see scan_kernel) when possible
-    if (nchunks >= 16) {
-        int64_t n8 = (nchunks + 7) / 8 * 8;
-        if (n8 * G <= 1024 && g.nspans / n8 >= 1) nchunks = n8;   // (more chunks only add superbins)
-    }
-    g.nchunks = (int)nchunks;
-    g.spc = (int)(g.nspans / nchunks);
-    g.rem = (int)(g.nspans - (int64_t)g.spc * nchunks);
-    if (g.spc < 1) return g;
-    const int nsb = G * g.nchunks;
-    g.vpl = 1;
-    while (g.vpl * 64 < nsb) g.vpl *= 2;
-    if (g.vpl > 16) return g;
-    g.ok = true;
-    return g;
-}
-
-// Direct-bin geometry: when N/256 superbins cannot outnumber k four to one, level-1 bins of 128 or 64 rows serve as
-// the superbins themselves (SelectArgs.direct_rows, up to 2048 of them); the chunking then only shapes the grid.
-// Returns the rows per bin, 0 if not applicable.
-int scan_geometry_direct(const vdb_index_s *h, int k, ScanGeom &g) {
-    const int G = h->tile16 ? 4 : 2;
-    // kernels with the finer bins: scan_kernel<.., BT> (32-row tiles, D <= 128) and scan16_kloop_kernel<.., FP> (p16, D > 128)
-    if (h->tile16 != (h->ksteps > kMaxKSteps)) return 0;
-    const int64_t nspans = h->Npad / (G * kBinRows);
-    if (nspans * G < 16) return 0;
-    for (int rows : {128, 64}) {
-        const int64_t nb = nspans * G * (kBinRows / rows);
-        if (nb >= 4 * (int64_t)k && nb <= 2048) {
-            g = ScanGeom{};
-            g.nspans = nspans;
-            int64_t nchunks = (nspans * G + 31) / 32;                 // ~8192 rows per chunk
-            if (nchunks >= 16) nchunks = (nchunks + 7) / 8 * 8;
-            nchunks = std::max<int64_t>(1, std::min<int64_t>(nchunks, nspans));
-            g.nchunks = (int)nchunks;
-            g.spc = (int)(nspans / nchunks);
-            g.rem = (int)(nspans - (int64_t)g.spc * nchunks);
-            g.vpl = 1;
-            while (g.vpl * 64 < nb) g.vpl *= 2;
-            g.ok = true;
-            return rows;
-        }
-    }
-    return 0;
-}
-
-// scan kernel variants: {waves per workgroup, tiles per LDS stage, waves per SIMD}.  Variant 0 is the
-// production one; the others exist for the interleaved A/B in scripts/sweep_scan.py (7..9 are timing-only
-// ablations of variant 0 and return wrong results).
-struct ScanVariant { int nwaves, st, wps; };
-constexpr ScanVariant kScanVariants[] = {{8, 4, 2}, {4, 4, 2}, {8, 4, 2}, {8, 4, 2}, {8, 4, 2}, {4, 4, 2}, {8, 4, 2},
-                                         {8, 4, 2}, {8, 4, 2}, {8, 4, 2}};
-[[maybe_unused]] constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
-
-template <int KSTEPS>
-void launch_scan_k(int variant, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int bt = 16, int nw = 8) {
-    if (bt == 16 && variant == 0 && nw < 8) {   // small batch: 64 * nw queries per workgroup, only the tiles that hold queries
-        sa.nqtiles = (int)((sa.nq_valid + nw * 64 - 1) / (nw * 64));
-        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
-        if (nw == 1) scan_kernel<KSTEPS, 1, 4, 1><<<dim3(grid), dim3(64), 0, st>>>(sa);
-        else if (nw == 2) scan_kernel<KSTEPS, 2, 4, 1><<<dim3(grid), dim3(128), 0, st>>>(sa);
-        else scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa);
-        return;
-    }
-    if (bt != 16) {            // direct-bin mode: finer level-1 bins (8 or 4 tiles), production schedule only
-        sa.nqtiles = (int)(Qpad / 512);
-        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
-        if (bt == 8) scan_kernel<KSTEPS, 8, 4, 2, 0, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
-        else scan_kernel<KSTEPS, 8, 4, 2, 0, 4><<<dim3(grid), dim3(512), 0, st>>>(sa);
-        return;
-    }
-    const ScanVariant v = kScanVariants[variant];
-    sa.nqtiles = (int)(Qpad / (v.nwaves * 64));
-    const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
-    switch (variant) {
-#ifdef VDB_ABLATIONS   // A/B schedules and timing-only ablations (WRONG RESULTS for 4, 7..9): scripts/sweep_scan.py builds
-        case 1: scan_kernel<KSTEPS, 4, 4, 2><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
-        case 4: scan_kernel<KSTEPS, 8, 4, 2, 5><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 5: scan_kernel<KSTEPS, 4, 4, 2, 0, 16, false, 3><<<dim3(grid), dim3(256), 0, st>>>(sa); break;
-        case 2: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 3: scan_kernel<KSTEPS, 8, 4, 2, 0, 16, false, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 6: scan_kernel<KSTEPS, 8, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 7: scan_kernel<KSTEPS, 8, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 8: scan_kernel<KSTEPS, 8, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-        case 9: scan_kernel<KSTEPS, 8, 4, 2, 3><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-#endif
-        default: scan_kernel<KSTEPS, 8, 4, 2><<<dim3(grid), dim3(512), 0, st>>>(sa); break;
-    }
-}
-
-void launch_scan(vdb_index_s *h, ScanArgs &sa, int nchunks, int64_t Qpad, hipStream_t st, int direct_rows = 0, int nw = 8) {
-    const int bt = direct_rows ? direct_rows / 16 : 16;       // 32-row-tile layout: tiles per level-1 bin
-    if (h->ksteps > kMaxKSteps) {  // D > 128
-        // scan_variant: 0 = 4 row tiles x 2 query blocks per wave (512-query tiles), 1 = 8 x 1 (256-query tiles);
-        // option kloop_qgroup = query tiles per group of the block order (0 -> default)
-        const bool wide = h->tile16 || (h->scan_variant != 1 && h->scan_variant != 4);   // 512-query tiles
-        sa.nqtiles = (int)(Qpad / (wide ? 512 : 256));
-        int qgroup = h->kloop_qgroup > 0 ? h->kloop_qgroup : (wide ? 4 : sa.nqtiles);
-        qgroup = std::min(qgroup, sa.nqtiles);
-        const unsigned ngroups = (unsigned)((sa.nqtiles + qgroup - 1) / qgroup);
-        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * ngroups * (unsigned)qgroup;
-        const ScanKloopExtra ex{h->ksteps, qgroup};
-        if (h->tile16 && direct_rows) {      // finer level-1 bins (production schedule only)
-            if (direct_rows == 128) scan16_kloop_kernel<0, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
-            else scan16_kloop_kernel<0, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
-            VDB_HIP(hipGetLastError());
-            return;
-        }
-        if (h->tile16) {
-            switch (h->scan_variant) {
-#ifdef VDB_ABLATIONS
-                case 2: scan16_kloop_kernel<0, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
-                case 7: scan16_kloop_kernel<2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
-                case 8: scan16_kloop_kernel<3, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
-                case 9: scan16_kloop_kernel<4, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
-#endif
-                default:
-                    if (sa.nq_valid > 0 && sa.nq_valid <= 16 && h->ksteps / 2 <= kNarrowMaxKS && !h->small_batch_off)
-                        scan16_kloop_kernel<0, 3, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
-                    else if (sa.nq_valid > 0 && sa.nq_valid < 64 && !h->small_batch_off)
-                        scan16_kloop_kernel<0, 2, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
-                    else
-                        scan16_kloop_kernel<0, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex);
-                    break;
-            }
-            VDB_HIP(hipGetLastError());
-            return;
-        }
-        switch (h->scan_variant) {
-#ifdef VDB_ABLATIONS
-            case 1: scan_kloop_kernel<0, 8, 1, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
-            case 2: scan_kloop_kernel<0, 4, 2, 2><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
-            case 3: scan_kloop_kernel<0, 4, 2, 4><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
-            case 4: scan_kloop_kernel<0, 4, 2, 1, true, 4><<<dim3(grid), dim3(256), 0, st>>>(sa, ex); break;
-            case 9: scan_kloop_kernel<4, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no epilogue
-            case 7: scan_kloop_kernel<2, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no MFMA
-            case 8: scan_kloop_kernel<3, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;  // no traffic
-#endif
-            default: scan_kloop_kernel<0, 4, 2, 1><<<dim3(grid), dim3(512), 0, st>>>(sa, ex); break;
-        }
-    } else if (h->tile16) {            // D <= 128 on p16 panels
-        sa.nqtiles = (int)(Qpad / 512);
-        const unsigned grid = 8u * (unsigned)((nchunks + 7) / 8) * (unsigned)sa.nqtiles;
-        const int v = h->scan_variant;
-        (void)v;
-        if (h->ksteps == 4) {
-#ifdef VDB_ABLATIONS
-            if (v == 7) scan16_kernel<2, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else if (v == 8) scan16_kernel<2, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else
-#endif
-            scan16_kernel<2, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
-        } else {
-#ifdef VDB_ABLATIONS
-            if (v == 7) scan16_kernel<4, 8, 1><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else if (v == 8) scan16_kernel<4, 8, 2><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else if (v == 1) scan16_kernel<4, 4><<<dim3(grid), dim3(512), 0, st>>>(sa);
-            else
-#endif
-            scan16_kernel<4, 8><<<dim3(grid), dim3(512), 0, st>>>(sa);
-        }
-    } else if (h->ksteps == 4)
-        launch_scan_k<4>(h->scan_variant, sa, nchunks, Qpad, st, bt, nw);
-    else
-        launch_scan_k<8>(h->scan_variant, sa, nchunks, Qpad, st, bt, nw);
-    VDB_HIP(hipGetLastError());
-}
-
-template <int VPL>
-void launch_select(const SelectArgs &a, hipStream_t st) {
-    select_kernel<VPL><<<dim3((unsigned)((a.nq + 3) / 4)), dim3(256), 0, st>>>(a);
-}
-
-long timing_begin(vdb_index_s *h, hipStream_t st) {
-    if (!h->timing || h->ev_used >= kMaxTimedCalls) return -1;
-    const size_t slot = h->ev_used++;
-    while (h->ev_scan.size() < 2 * (slot + 1)) {
-        hipEvent_t e;
-        VDB_HIP(hipEventCreate(&e));
-        h->ev_scan.push_back(e);
-        VDB_HIP(hipEventCreate(&e));
-        h->ev_total.push_back(e);
-    }
-    VDB_HIP(hipEventRecord(h->ev_total[2 * slot], st));
-    return (long)slot;
-}
-
-// which: 0 = dominant kernel starts, 1 = dominant kernel done, 2 = pipeline done
-void timing_mark(vdb_index_s *h, long slot, int which, hipStream_t st) {
-    if (slot < 0) return;
-    hipEvent_t e = which == 0 ? h->ev_scan[2 * slot] : which == 1 ? h->ev_scan[2 * slot + 1] : h->ev_total[2 * slot + 1];
-    VDB_HIP(hipEventRecord(e, st));
-}
-
-// ---- one query batch ---------------------------------------------------------------------------------
-// outputs: final (D,I) or partial (pk,pi); all device pointers for rows [0,nq) of this batch
-void search_batch(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, int64_t *I, double *pk, int64_t *pi,
-                  hipStream_t st) {
-    Workspace &ws = h->ws;
-    const int Dm = h->dim, D4 = h->D4;
-    // float32 queries padded to D4 for the refine kernels
-    const float *qpad = dq;
-    if (D4 != Dm) {
-        ws.qpad.reserve((size_t)nq * D4 * sizeof(float));
-        pad_rows_kernel<<<dim3((unsigned)((nq * D4 + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, D4, ws.qpad.as<float>());
-        VDB_HIP(hipGetLastError());
-        qpad = ws.qpad.as<float>();
-    }
-    RefineCommon rc{h->x32.as<float>(), qpad, h->N, h->id_base, D4, h->metric, k, nullptr};
-    rc.info = batch_info(ws);                             // (group size of the candidates: 4 rows, 8 on the int8 scan)
-    if (h->i8_ok && h->rows8.p && !h->i8_disable) {       // (used only by batches the device puts on the int8 scan)
-        rc.X8 = h->rows8.as<signed char>();
-        rc.rowstat = h->rowstat8.as<int>();
-        rc.x8_pitch = h->rows8_pitch;
-        rc.cx = h->i8_cx;
-        rc.D = Dm;
-        ws.qrows8.reserve((size_t)nq * h->rows8_pitch);
-        rc.Q8 = ws.qrows8.as<signed char>();               // (filled next to the B fragments when the int8 scan is offered)
-    }
-
-    ScanGeom g;
-    const bool exact_only = h->force_path == 1 || h->force_path == 3;   // 3: also without query blocking (A/B runs)
-    bool use_scan = h->scan_ok && !exact_only && k <= 1024;
-    int direct_rows = 0;
-    if (use_scan) {
-        g = scan_geometry(h, k, nq);
-        if (!g.ok) direct_rows = scan_geometry_direct(h, k, g);
-    }
-    // (measured on 1M x 128 with host I/O: the MFMA pipeline answers 1..512 queries in 0.13..0.18 ms, the exhaustive float64
-    //  kernel needs 0.3 ms for one query -- scripts/latency_small_batches.py -- so the batch size does not gate the path)
-    // Between the dense small-corpus path (<= 8192 rows) and 32768 rows the scan pays off once the batch carries
-    // enough (query, row) pairs: ~0.3 ms of fixed pipeline cost against ~7e-8 ms per pair in the exhaustive kernel.
-    use_scan = use_scan && g.ok &&
-               (h->force_path == 2 || h->N >= 32768 || (h->Npad > 8192 && (double)nq * (double)h->N >= 4.0e6));
-    // (corpora of 8193..15360 rows whose chunking cannot give 4k superbins still have the dense path below)
-
-    h->info_valid_nq = -1;
-    // fb_count restarts with every batch (it indexes this batch's fb_list); the statistics counters behind it were
-    // zeroed once for the whole call (search_device_impl) and accumulate over the batches
-    if (h->small_is_clean) h->small_is_clean = false;      // the first batch of a call: search_device_impl has just cleared all of it
-    else VDB_HIP(hipMemsetAsync(ws.small.p, 0, 64, st));
-    int32_t *fb_count = ws.small.as<int32_t>();
-    unsigned long long *stat_counters = reinterpret_cast<unsigned long long *>(ws.small.as<char>() + 64);
-
-    const long tslot = timing_begin(h, st);
-
-    // small corpora: dense fp16 scores + per-query guard + exact re-score of the few surviving rows
-    const bool use_dense = !use_scan && h->scan_ok && !exact_only && h->ksteps <= kMaxKSteps &&
-                           h->Npad <= kDenseMaxRows && nq >= 64 && k <= 1024 && (int64_t)k * 2 <= h->N &&
-                           !h->tile16 && (h->Npad + std::max(128, 2 * k + 64)) * 4 <= 65536;   // scores + candidates in LDS
-    if (use_dense) {
-        const int64_t Qp = (nq + 63) / 64 * 64;
-        const int cand_cap = std::max(128, 2 * k + 64);
-        ws.qpanels.reserve((size_t)(Qp / 32) * h->ksteps * 64 * sizeof(half8));
-        ws.eps.reserve((size_t)nq * sizeof(float));
-        ws.dense.reserve((size_t)Qp * h->Npad * sizeof(float));
-        ws.fallback.reserve((size_t)nq * sizeof(int32_t));
-        ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
-        QueryBatchInfo *info = batch_info(ws);          // (zeroed with fb_count above)
-        const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
-            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2, 0});
-        h->info_valid_nq = nq;
-        const int64_t threads = (Qp / 32) * h->ksteps * 64;
-        build_qpanels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(
-            dq, nq, Dm, D4, h->ksteps, Qp / 32, info, ws.qpanels.as<half8>());
-        EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
-                   h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
-        query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
-        const int64_t ntiles = h->Npad / kTileRows;
-        timing_mark(h, tslot, 0, st);
-        {
-            const dim3 grid((unsigned)((ntiles + 3) / 4), (unsigned)(Qp / 64));
-            if (h->ksteps == 4)
-                dense_scores_kernel<4><<<grid, dim3(256), 0, st>>>(h->panels.as<half8>(), h->bias.as<float>(),
-                                                                  ws.qpanels.as<half8>(), info, ntiles, h->Npad,
-                                                                  ws.dense.as<float>());
-            else
-                dense_scores_kernel<8><<<grid, dim3(256), 0, st>>>(h->panels.as<half8>(), h->bias.as<float>(),
-                                                                  ws.qpanels.as<half8>(), info, ntiles, h->Npad,
-                                                                  ws.dense.as<float>());
-        }
-        timing_mark(h, tslot, 1, st);
-        DenseSelectArgs da{};
-        da.c = rc;
-        da.scores = ws.dense.as<float>();
-        da.eps = ws.eps.as<float>();
-        da.info = info;
-        da.nq = nq;
-        da.Npad = h->Npad;
-        da.cand_cap = cand_cap;
-        da.fallback = ws.fallback.as<int32_t>();
-        da.fb_list = ws.fb_list.as<int32_t>();
-        da.fb_count = fb_count;
-        da.stat_counters = stat_counters;
-        da.D = D;
-        da.I = I;
-        da.pkeys = pk;
-        da.pids = pi;
-        da.set_only = (h->set_only && D != nullptr) ? 1 : 0;
-        {
-            const int kpl = kpl_for(k);
-            if (h->Npad <= 2048 && kpl <= 4) {       // scores in registers, 4 queries per workgroup (dense.hpp)
-                const dim3 g4((unsigned)((nq + 3) / 4));
-                const size_t lds4 = (size_t)4 * 2 * cand_cap * 4;       // per wave: candidate rows + their keys
-                if (h->Npad <= 1024) {
-                    DISPATCH_KPL(kpl, (dense_select_reg_kernel<(KPL <= 4 ? KPL : 4), 16><<<g4, dim3(256), lds4, st>>>(da)));
-                } else {
-                    DISPATCH_KPL(kpl, (dense_select_reg_kernel<(KPL <= 4 ? KPL : 4), 32><<<g4, dim3(256), lds4, st>>>(da)));
-                }
-            } else {
-                const size_t lds = (size_t)(h->Npad + cand_cap) * 4;
-                DISPATCH_KPL(kpl, (dense_select_kernel<KPL><<<dim3((unsigned)nq), dim3(64), lds, st>>>(da)));
-            }
-            VDB_HIP(hipGetLastError());
-        }
-        // queries whose candidate list overflowed (or unusable scales): exhaustive exact pass
-        int64_t S = std::min<int64_t>(16, std::max<int64_t>(1, h->N / 1024));
-        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
-        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
-        ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
-        ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
-        RefineFullArgs fa{};
-        fa.c = rc;
-        fa.qlist = da.fb_list;
-        fa.count_ptr = fb_count;
-        fa.S = (int)S;
-        fa.rows_per_split = (h->N + S - 1) / S;
-        if (S == 1 && D) {       // one split: the exhaustive pass writes the final rows itself, nothing to merge
-            fa.D = D;
-            fa.I = I;
-            launch_refine_full(fa, 1024, st);
-        } else {
-            fa.pkeys = ws.pkeys.as<double>();
-            fa.pids = ws.pids.as<int64_t>();
-            launch_refine_full(fa, 1024, st);
-            MergeArgs ma{};
-            ma.pkeys = fa.pkeys;
-            ma.pids = fa.pids;
-            ma.part_stride = k;
-            ma.slot_stride = S * k;
-            ma.nparts = (int)S;
-            ma.k = k;
-            ma.metric = h->metric;
-            ma.qlist = da.fb_list;
-            ma.count_ptr = fb_count;
-            ma.D = D;
-            ma.I = I;
-            ma.okeys = pk;
-            ma.oids = pi;
-            launch_merge(ma, 256, st);
-        }
-        timing_mark(h, tslot, 2, st);
-        h->last.last_path = VDB_PATH_MFMA_SCAN;
-        return;
-    }
-
-    if (!use_scan) {
-        // exhaustive exact scan, split over S waves per query (per group of 4 queries in the query-blocked form,
-        // which fetches every row once for the four: k <= 128, at least 4 queries)
-        // (it needs enough (group, split) units to fill the chip: small corpora and tiny batches keep the one-query form)
-        bool blocked = kpl_for(k) <= 2 && nq >= 2 * kRefineQB && h->force_path != 3;
-        if (blocked) {
-            const int64_t g4 = (nq + kRefineQB - 1) / kRefineQB;
-            const int64_t s4 = std::min<int64_t>((4096 + g4 - 1) / g4, std::max<int64_t>(1, h->N / 2048));
-            blocked = g4 * s4 >= 1024;
-        }
-        const int64_t ngroups = blocked ? (nq + kRefineQB - 1) / kRefineQB : nq;
-        auto launch_full = [&](const RefineFullArgs &fa) {
-            if (blocked) launch_refine_full_blocked(fa, ngroups * fa.S, st);
-            else launch_refine_full(fa, nq * fa.S, st);
-        };
-        int64_t S = ((blocked ? 4096 : 8192) + ngroups - 1) / ngroups;
-        // (a split is worth >= 1024 rows; the blocked form merges 4x the partial lists per unit, so its splits are larger)
-        S = std::min<int64_t>(S, std::max<int64_t>(1, h->N / (blocked ? 2048 : 1024)));
-        // a handful of queries on a small corpus (an IVF coarse quantizer asked for 1..63 queries): one wave per query
-        // would walk all rows alone (92 us for 8 queries x 1024 centroids) -- up to 64 splits of >= 128 rows instead
-        if (!blocked && nq < 64) S = std::max<int64_t>(S, std::min<int64_t>(64, h->N / 128));
-        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
-        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
-        RefineFullArgs fa{};
-        fa.c = rc;
-        fa.count = nq;
-        fa.S = (int)S;
-        fa.rows_per_split = ((h->N + S - 1) / S + 63) / 64 * 64;     // whole 64-row wave iterations
-        if (fa.rows_per_split < 64) fa.rows_per_split = 64;
-        timing_mark(h, tslot, 0, st);
-        if (S == 1 && D) {
-            fa.D = D;
-            fa.I = I;
-            launch_full(fa);
-        } else if (S == 1) {
-            fa.pkeys = pk;
-            fa.pids = pi;
-            launch_full(fa);
-        } else {
-            ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
-            ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
-            fa.pkeys = ws.pkeys.as<double>();
-            fa.pids = ws.pids.as<int64_t>();
-            launch_full(fa);
-            MergeArgs ma{};
-            ma.pkeys = fa.pkeys;
-            ma.pids = fa.pids;
-            ma.part_stride = k;
-            ma.slot_stride = S * k;
-            ma.nparts = (int)S;
-            ma.k = k;
-            ma.metric = h->metric;
-            ma.count = nq;
-            ma.D = D;
-            ma.I = I;
-            ma.okeys = pk;
-            ma.oids = pi;
-            launch_merge(ma, nq, st);
-        }
-        h->last.last_path = VDB_PATH_EXACT_SCAN;
-        timing_mark(h, tslot, 1, st);
-        timing_mark(h, tslot, 2, st);
-        return;
-    }
-
-    // ---- MFMA scan path ------------------------------------------------------------------------------
-    const int64_t Qpad = (nq + 511) / 512 * 512;
-    const int G = h->tile16 ? 4 : 2;
-    const int64_t nbins = g.nspans * G * (direct_rows ? kBinRows / direct_rows : 1), nsb = (int64_t)g.nchunks * G;
-    const int cand_cap = h->list_cap > 0 ? h->list_cap : std::max(64, 2 * k + 32);
-    const int rescan_cap = std::max(16, k / 2 + 8);
-    // int8 scan for byte-valued corpora: offered to the device-side choice whenever the standard geometry is in use
-    const bool use_i8 = h->i8_ok && !h->i8_disable && !direct_rows && !h->tile16 && h->scan_variant == 0;
-    ws.qpanels.reserve((size_t)(Qpad / 32) * h->ksteps * 64 * sizeof(half8));
-    ws.eps.reserve((size_t)nq * sizeof(float));
-    ws.bin_m1.reserve((size_t)nbins * Qpad * sizeof(float));
-    ws.bin_m2.reserve((size_t)nbins * Qpad * sizeof(float));
-    ws.sb_m1.reserve((size_t)nsb * Qpad * sizeof(float));
-    ws.sb_m2.reserve((size_t)nsb * Qpad * sizeof(float));
-    ws.sb_span.reserve((size_t)nsb * Qpad * sizeof(int32_t));
-    ws.cand.reserve((size_t)nq * cand_cap * sizeof(int32_t));
-    ws.rescan.reserve((size_t)nq * rescan_cap * 2 * sizeof(int32_t));
-    ws.counts.reserve((size_t)nq * 2 * sizeof(int32_t));
-    ws.fallback.reserve((size_t)nq * sizeof(int32_t));
-    ws.fb_list.reserve((size_t)nq * sizeof(int32_t));
-
-    QueryBatchInfo *info = batch_info(ws);              // (zeroed with fb_count above)
-    {
-        const int64_t total = nq * Dm;
-        query_stats_kernel<<<dim3(query_stats_blocks(total)), dim3(256), 0, st>>>(dq, total, info,
-            FinalizeArgs{h->sx, h->metric, h->corpus_int_unscaled ? 1 : 0, h->maxnorm2,
-                         use_i8 ? (1 | (h->i8_group == 8 ? 4 : 0)) : 0});
-        h->info_valid_nq = nq;
-        EpsArgs ea{dq, nq, Dm, h->ksteps * 16, h->metric, sqrtf(h->maxnorm2) * 1.0000002f,
-                   h->corpus_fp16_exact ? 1 : 0, h->corpus_int_unscaled ? 1 : 0, h->sx, info, ws.eps.as<float>()};
-        const int64_t threads = (Qpad / 32) * h->ksteps * 64;      // (same element count in both layouts)
-        if (h->tile16) {
-            build_qpanels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(dq, nq, Dm, h->ksteps / 2, Qpad / 16, info, ws.qpanels.as<half8>());
-            query_eps_kernel<<<dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st>>>(ea);
-        } else {            // one dispatch: fp16 fragments | int8 fragments | int8 query rows | error bounds (scan_i8.hpp)
-            QueryPrepArgs qp{};
-            qp.Q = dq; qp.nq = nq; qp.nqtiles = Qpad / 32;
-            qp.D = Dm; qp.D4 = D4; qp.ksteps = h->ksteps; qp.ks32 = h->i8_ks; qp.pitch8 = h->rows8_pitch;
-            qp.info = info;
-            qp.qpanels = ws.qpanels.as<half8>();
-            qp.eps = ea;
-            unsigned nblk = (unsigned)((threads + 255) / 256);
-            qp.nA = nblk;
-            if (use_i8) {   // (the int8 regions return at once unless the device chose the int8 scan for this batch)
-                ws.qpanels8.reserve((size_t)(Qpad / 32) * h->i8_ks * 64 * sizeof(int4v));
-                qp.qpanels8 = ws.qpanels8.as<int4v>();
-                nblk += (unsigned)(((Qpad / 32) * h->i8_ks * 64 + 255) / 256);
-            }
-            qp.nB = nblk;
-            if (use_i8 && rc.Q8) {
-                qp.qrows8 = ws.qrows8.as<signed char>();
-                nblk += (unsigned)((nq * h->rows8_pitch + 255) / 256);
-            }
-            qp.nC = nblk;
-            nblk += (unsigned)((nq * 16 + 255) / 256);
-            query_prep_kernel<<<dim3(nblk), dim3(256), 0, st>>>(qp);
-        }
-        VDB_HIP(hipGetLastError());
-    }
-
-    ScanArgs sa{};
-    sa.panels = h->panels.as<half8>();
-    sa.bias = h->bias.as<float>();
-    sa.qpanels = ws.qpanels.as<half8>();
-    sa.info = info;
-    sa.bin_m1 = ws.bin_m1.as<float>();
-    sa.bin_m2 = ws.bin_m2.as<float>();
-    sa.sb_m1 = ws.sb_m1.as<float>();
-    sa.sb_m2 = ws.sb_m2.as<float>();
-    sa.sb_span = ws.sb_span.as<int32_t>();
-    sa.nspans = g.nspans;
-    sa.spans_per_chunk = g.spc;
-    sa.chunk_rem = g.rem;
-    sa.nchunks = g.nchunks;
-    sa.Qpad = Qpad;
-    sa.nq_valid = nq;
-    if (h->scan_variant == 6) {   // diagnostic build: per-wave cycle sums
-        const size_t nblocks = 8 * (size_t)((g.nchunks + 7) / 8) * (size_t)(Qpad / 512);
-        ws.dense.reserve(nblocks * 8 * 8 * sizeof(unsigned long long));
-        VDB_HIP(hipMemsetAsync(ws.dense.p, 0, nblocks * 8 * 8 * sizeof(unsigned long long), st));
-        sa.dbg = ws.dense.as<unsigned long long>();
-        h->dbg_words = nblocks * 8 * 8;
-    }
-    timing_mark(h, tslot, 0, st);
-    // small batches: as many waves per workgroup as there are 64-query column groups (1, 2, 4; 8 = the batch shape)
-    const int nw_small = h->small_batch_off ? 8 : nq <= 64 ? 1 : nq <= 128 ? 2 : nq <= 256 ? 4 : 8;
-    launch_scan(h, sa, g.nchunks, Qpad, st, direct_rows, nw_small);   // (fp16: returns at once when the int8 scan serves the batch)
-    if (use_i8) {
-        ScanI8Args s8{};
-        s8.panels = h->panels8.as<int4v>();
-        s8.bias8 = h->bias8.as<int32_t>();
-        s8.qpanels = ws.qpanels8.as<int4v>();
-        s8.info = info;
-        s8.bin_m1 = sa.bin_m1; s8.bin_m2 = sa.bin_m2;
-        s8.sb_m1 = sa.sb_m1; s8.sb_m2 = sa.sb_m2; s8.sb_span = sa.sb_span;
-        s8.nspans = g.nspans; s8.Npad = h->Npad; s8.Qpad = Qpad; s8.nq_valid = nq;
-        s8.spans_per_chunk = g.spc; s8.chunk_rem = g.rem; s8.nchunks = g.nchunks;
-        // i8_variant (tuning, every variant exact; scripts/sweep_i8.py): 0 = 512-query tiles (2 column blocks per wave),
-        // 4-tile stages; 1 = 8-tile stages; 2 = 1024-query tiles (4 column blocks per wave); 3 = both (default);
-        // 4 / 5 = 16 waves per workgroup (4 per SIMD) with 8- / 16-tile stages.  Odd batch sizes keep 512-query tiles.
-        int v8 = h->i8_variant;
-#ifdef VDB_ABLATIONS
-        s8.abl_no_bins = (v8 & 8) ? 1 : 0;      // +8: no level-1 bin stores (timing only, WRONG results)
-        v8 &= 7;
-#endif
-        if (Qpad % 1024 != 0) v8 &= 1;
-        if ((int64_t)g.nchunks * (Qpad / 1024) < 256) v8 &= 1;     // too few 1024-query tiles to cover the chip: 512-query tiles
-        if (nw_small < 8) v8 = 8 + nw_small;
-        const int qtile = (v8 > 8) ? 64 * nw_small : (v8 >= 2) ? 1024 : 512;
-        s8.nqtiles = (int)((v8 > 8 ? nq + qtile - 1 : Qpad) / qtile);
-        const dim3 grid8(8u * (unsigned)((g.nchunks + 7) / 8) * (unsigned)s8.nqtiles);
-#define VDB_I8G(KS_, ST_, CB_, NW_, G_) scan_i8_kernel<KS_, ST_, CB_, NW_, 16, false, G_><<<grid8, dim3(NW_ * 64), 0, st>>>(s8)
-#define VDB_I8(KS_, ST_, CB_, NW_) do { if (h->i8_group == 8) VDB_I8G(KS_, ST_, CB_, NW_, 8); else VDB_I8G(KS_, ST_, CB_, NW_, 4); } while (0)
-        if (h->i8_ks == 2) {
-            switch (v8) { case 1: VDB_I8(2, 8, 2, 8); break; case 2: VDB_I8(2, 4, 4, 8); break; case 3: VDB_I8(2, 8, 4, 8); break;
-                          case 4: VDB_I8(2, 8, 2, 16); break; case 5: VDB_I8(2, 16, 2, 16); break;
-                          case 9: VDB_I8(2, 4, 2, 1); break; case 10: VDB_I8(2, 4, 2, 2); break; case 12: VDB_I8(2, 4, 2, 4); break;
-                          default: VDB_I8(2, 4, 2, 8); }
-        } else {
-            switch (v8) { case 1: VDB_I8(4, 8, 2, 8); break; case 2: VDB_I8(4, 4, 4, 8); break; case 3: VDB_I8(4, 8, 4, 8); break;
-                          case 4: VDB_I8(4, 8, 2, 16); break; case 5: VDB_I8(4, 16, 2, 16); break;
-                          case 9: VDB_I8(4, 4, 2, 1); break; case 10: VDB_I8(4, 4, 2, 2); break; case 12: VDB_I8(4, 4, 2, 4); break;
-                          default: VDB_I8(4, 4, 2, 8); }
-        }
-#undef VDB_I8G
-#undef VDB_I8
-        VDB_HIP(hipGetLastError());
-    }
-    timing_mark(h, tslot, 1, st);
-
-    SelectArgs se{};
-    se.bin_m1 = sa.bin_m1;
-    se.bin_m2 = sa.bin_m2;
-    se.sb_m1 = sa.sb_m1;
-    se.sb_m2 = sa.sb_m2;
-    se.sb_span = sa.sb_span;
-    se.eps = ws.eps.as<float>();
-    se.info = info;
-    se.nq = nq;
-    se.Qpad = Qpad;
-    se.nspans = g.nspans;
-    se.N = h->N;
-    se.spans_per_chunk = g.spc;
-    se.chunk_rem = g.rem;
-    se.nchunks = g.nchunks;
-    se.k = k;
-    se.groups = G;
-    se.direct_rows = direct_rows;
-    if (direct_rows) {        // the level-1 bins are the superbins
-        se.sb_m1 = sa.bin_m1;
-        se.sb_m2 = sa.bin_m2;
-    }
-    se.cand_cap = cand_cap;
-    se.rescan_cap = rescan_cap;
-    se.cand_rows = ws.cand.as<int32_t>();
-    se.rescan_rows = ws.rescan.as<int32_t>();
-    se.counts = ws.counts.as<int32_t>();
-    se.fallback = ws.fallback.as<int32_t>();
-    se.fb_list = ws.fb_list.as<int32_t>();
-    se.fb_count = fb_count;
-    se.stat_counters = stat_counters;
-    const int nsb_i = G * g.nchunks;
-    if (nsb_i > 128 && nsb_i <= 256 && h->select_variant == 2 && !direct_rows) {   // 32 lanes per query, 2 queries per wave
-        select_kernel_v2<8, 32><<<dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, st>>>(se);
-    } else if (nsb_i <= 256 && h->select_variant != 1 && !direct_rows) {  // multi-lane form: 16 lanes per query, 4 queries per wave
-        const unsigned sgrid = (unsigned)((nq + 15) / 16);
-        if (nsb_i <= 64)
-            select_kernel_v2<4, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
-        else if (nsb_i <= 128)
-            select_kernel_v2<8, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
-        else
-            select_kernel_v2<16, 16><<<dim3(sgrid), dim3(256), 0, st>>>(se);
-    } else {
-        switch (g.vpl) {
-            case 1: launch_select<1>(se, st); break;
-            case 2: launch_select<2>(se, st); break;
-            case 4: launch_select<4>(se, st); break;
-            case 8: launch_select<8>(se, st); break;
-            case 16: launch_select<16>(se, st); break;
-            default: launch_select<32>(se, st); break;
-        }
-    }
-    VDB_HIP(hipGetLastError());
-
-    RefineListArgs la{};
-    la.c = rc;
-    la.nq = nq;
-    la.cand_rows = se.cand_rows;
-    la.rescan_rows = se.rescan_rows;
-    la.counts = se.counts;
-    la.fallback = se.fallback;
-    la.cand_cap = cand_cap;
-    la.rescan_cap = rescan_cap;
-    la.D = D;
-    la.I = I;
-    la.pkeys = pk;
-    la.pids = pi;
-    {
-        const int kpl = kpl_for(k);
-        DISPATCH_KPL(kpl, (refine_list_kernel<KPL><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st>>>(la)));
-        VDB_HIP(hipGetLastError());
-    }
-
-    // queries whose work list overflowed (or whose scales were unusable): exhaustive exact pass
-    {
-        int64_t S = std::min<int64_t>(64, std::max<int64_t>(1, h->N / 4096));
-        const int64_t cap = std::max<int64_t>(1, (int64_t)(256ll << 20) / (nq * k * 16));
-        S = std::max<int64_t>(1, std::min<int64_t>(S, cap));
-        ws.pkeys.reserve((size_t)nq * S * k * sizeof(double));
-        ws.pids.reserve((size_t)nq * S * k * sizeof(int64_t));
-        RefineFullArgs fa{};
-        fa.c = rc;
-        fa.qlist = se.fb_list;
-        fa.count_ptr = fb_count;
-        fa.S = (int)S;
-        fa.rows_per_split = (h->N + S - 1) / S;
-        fa.pkeys = ws.pkeys.as<double>();
-        fa.pids = ws.pids.as<int64_t>();
-        launch_refine_full(fa, 1024, st);
-        MergeArgs ma{};
-        ma.pkeys = fa.pkeys;
-        ma.pids = fa.pids;
-        ma.part_stride = k;
-        ma.slot_stride = S * k;
-        ma.nparts = (int)S;
-        ma.k = k;
-        ma.metric = h->metric;
-        ma.qlist = se.fb_list;
-        ma.count_ptr = fb_count;
-        ma.D = D;
-        ma.I = I;
-        ma.okeys = pk;
-        ma.oids = pi;
-        launch_merge(ma, 256, st);
-    }
-    timing_mark(h, tslot, 2, st);
-    h->last.last_path = VDB_PATH_MFMA_SCAN;
-}
-
-// ---- hipGraph replay of a repeated device-resident search -----------------------------------------------------------
-// A small batch is a chain of ~9 (flat) / ~18 (IVF) short dependent dispatches.  With option "graph" = 1 the first call
-// of a (buffers, shape, stream) combination runs eagerly (it sizes the workspace: allocation is illegal while capturing),
-// the second is captured into a graph and launched, later ones replay the graph.  Anything that changes the index or an
-// option drops the graph (graph_reset).
-void graph_reset(vdb_index_s *h) {
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-    h->graph_key = vdb_index_s::GraphKey{};
-    h->graph_warm = vdb_index_s::GraphKey{};
-}
-
-constexpr int64_t kGraphMaxQueries = 4096;
-
-template <class F>
-void graph_or_run(vdb_index_s *h, const vdb_index_s::GraphKey &key, F &&run) {
-    const bool eligible = h->graph_mode && key.st != nullptr && !h->timing && key.nq > 0 && key.nq <= kGraphMaxQueries;
-    if (!eligible) {
-        run();
-        return;
-    }
-    if (h->graph_exec && key == h->graph_key && h->graph_epoch == g_alloc_epoch.load(std::memory_order_relaxed)) {
-        VDB_HIP(hipGraphLaunch(h->graph_exec, key.st));
-        ++h->graph_replays;
-        return;
-    }
-    if (h->graph_exec) {      // another shape, or a buffer moved since the capture (the graph holds raw addresses): drop it
-        (void)hipGraphExecDestroy(h->graph_exec);
-        h->graph_exec = nullptr;
-        h->graph_key = vdb_index_s::GraphKey{};
-    }
-    if (!(key == h->graph_warm)) {
-        run();
-        h->graph_warm = key;
-        return;
-    }
-    const vdb_index_s::GraphKey warm = h->graph_warm;
-    graph_reset(h);
-    VDB_HIP(hipStreamBeginCapture(key.st, hipStreamCaptureModeThreadLocal));
-    hipGraph_t g = nullptr;
-    bool captured = true;
-    try {
-        run();
-    } catch (...) {
-        captured = false;
-    }
-    const hipError_t e_end = hipStreamEndCapture(key.st, &g);
-    hipGraphExec_t ex = nullptr;
-    if (captured && e_end == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-        (void)hipGraphDestroy(g);
-        h->graph_exec = ex;
-        h->graph_key = key;
-        h->graph_warm = warm;
-        h->graph_epoch = g_alloc_epoch.load(std::memory_order_relaxed);
-        VDB_HIP(hipGraphLaunch(ex, key.st));
-        ++h->graph_replays;
-        return;
-    }
-    if (g) (void)hipGraphDestroy(g);
-    (void)hipGetLastError();
-    run();          // the capture did not work out (e.g. a workspace had to grow): this call runs eagerly, the next one warms up again
-}
-
-void search_device_impl(vdb_index_s *h, const float *dq, int64_t nq, int k, float *D, int64_t *I, double *pk,
-                        int64_t *pi, hipStream_t st) {
-    if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
-    if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
-    if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
-    h->last.last_nq = nq;
-    if (nq == 0) return;
-    if (!dq) throw Error(VDB_ERR_INVALID, "null query pointer");
-    if (h->N == 0) {  // empty shard: all padding
-        MergeArgs ma{};
-        ma.nparts = 0;
-        ma.k = k;
-        ma.metric = h->metric;
-        ma.count = nq;
-        ma.D = D;
-        ma.I = I;
-        ma.okeys = pk;
-        ma.oids = pi;
-        launch_merge(ma, nq, st);
-        h->last.last_path = VDB_PATH_EXACT_SCAN;
-        return;
-    }
-    // queries per pass: the level-1 bin arrays cost 8 bytes per (256-row bin, query); keep them within kBinBudget so
-    // that a large batch on a large shard is served in several passes instead of failing with VDB_ERR_NOMEM
-    int64_t kBatch = 16384;
-    {
-        const int64_t nbins = std::max<int64_t>(1, h->Npad / kBinRows);
-        const int64_t fit = (int64_t)(kBinBudget / (8.0 * (double)nbins)) / 512 * 512;
-        kBatch = std::max<int64_t>(512, std::min<int64_t>(kBatch, fit));
-    }
-    h->ws.small.reserve(kSmallBytes);
-    VDB_HIP(hipMemsetAsync(h->ws.small.p, 0, kSmallBytes, st));
-    h->small_is_clean = true;
-    const size_t ev_mark = h->ev_used;
-    try {
-        for (int64_t b0 = 0; b0 < nq; b0 += kBatch) {
-            const int64_t nb = std::min<int64_t>(kBatch, nq - b0);
-            search_batch(h, dq + (size_t)b0 * h->dim, nb, k, D ? D + (size_t)b0 * k : nullptr,
-                         I ? I + (size_t)b0 * k : nullptr, pk ? pk + (size_t)b0 * k : nullptr,
-                         pi ? pi + (size_t)b0 * k : nullptr, st);
-        }
-    } catch (...) {
-        h->ev_used = ev_mark;      // events of a failed search were never all recorded: do not leave them to vdb_stats
-        h->small_is_clean = false;
-        throw;
-    }
-    h->small_is_clean = false;
-}
+#include "search_flat.inc"   // scan geometry, launchers, search_batch, graph replay, search_device_impl
 
 template <class F>
 int guarded(F &&f) {
