@@ -280,8 +280,35 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (tid + i * NT < ST * 32)
                 lds_b(buf)[tid + i * NT] = (stage_b[i] >= 0.9e38f) ? kPadBias : stage_b[i] * cs;
     };
+    // ITEMS with 64-row bins (BPS = 4): the four bins of a span half are consecutive floats of the lane's slot, so they
+    // are collected in registers and stored as ONE 16-byte vector per array instead of four scattered 4-byte stores --
+    // in [item][slot][bin] order every lane writes its own line, and at one flush per 4 tiles those stores kept the
+    // CU's address path busy three quarters of the time (the list scan at nprobe 8 ran as long as at nprobe 32).
+    constexpr bool kVecBins = ITEMS && BPS == 4;
+    float4 pend1[2], pend2[2], pend3[2];
     // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
     auto flush_bin = [&](int64_t span, int bt) {
+        if (kVecBins) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                pend1[cb] = make_float4(pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]);
+                pend2[cb] = make_float4(pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]);
+                pend3[cb] = make_float4(pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]);
+                m1[cb] = INF;
+                m2[cb] = INF;
+                m3[cb] = INF;
+            }
+            if (bt == BPS - 1) {     // (the bins of a span half are always flushed in order 0..3 by the same wave)
+                const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    *reinterpret_cast<float4 *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                    *reinterpret_cast<float4 *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                    *reinterpret_cast<float4 *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
+                }
+            }
+            return;
+        }
         // flat: [bin][query] (coalesced over the 32 queries of a lane half).  ITEMS: [item][slot][bin] so
         // that the per-query select reads the bins of one probe as one contiguous run.
         const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +

@@ -321,8 +321,32 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         for (int i = 0; i < kBiasLoads; ++i)
             if (tid + i * NT < ST * 32) lds_b(buf)[tid + i * NT] = stage_b[i];
     };
+    // ITEMS with 64-row bins (BPS = 4): the four bins of a span half leave as ONE 16-byte store per array (see scan_kernel)
+    constexpr bool kVecBins = ITEMS && BPS == 4;
+    int4v pend1[CB], pend2[CB], pend3[CB];
     // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]; ITEMS: [item][slot][bin]
     auto flush_bin = [&](int64_t span, int bt) {
+        if (kVecBins) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                pend1[cb] = int4v{pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]};
+                pend2[cb] = int4v{pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]};
+                pend3[cb] = int4v{pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]};
+                m1[cb] = INF;
+                m2[cb] = INF;
+                m3[cb] = INF;
+            }
+            if (bt == BPS - 1) {
+                const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    *reinterpret_cast<int4v *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                    *reinterpret_cast<int4v *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                    *reinterpret_cast<int4v *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
+                }
+            }
+            return;
+        }
         const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
                                      (size_t)(((span - lspan0) * 2 + h) * BPS + bt)
                                : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
