@@ -233,21 +233,52 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restr
     }
 }
 
-// query rows the list scan gathers its B fragments from, [nq][Dpad]: scaled fp16 (fp16 scan) or, when the batch is on
-// the int8 scan (info->i8_mode) and q8 is given, int8 cq - q -- one kernel, whichever the device chose
-__global__ __launch_bounds__(256) void ivf_qrows_kernel(const float *__restrict__ Q, int64_t nq, int D, int Dpad,
-                                                        const QueryBatchInfo *__restrict__ info,
-                                                        _Float16 *__restrict__ qrows, signed char *__restrict__ q8) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * Dpad) return;
-    const int64_t q = i / Dpad;
-    const int d = (int)(i - q * Dpad);
+// One dispatch for what the list scan needs from the query batch: the scales (when the coarse search of this batch has
+// already taken the statistics of these queries: every workgroup finalises its own copy in LDS, workgroup 0 publishes
+// it for the kernels that follow), the per-query error bounds, and the query rows the list scan gathers its B fragments
+// from, [nq][Dpad]: scaled fp16, or int8 cq - q when the batch is on the int8 scan and q8 is given.  It replaces a
+// one-thread finalize kernel + query_eps_kernel + ivf_qrows_kernel (three dependent ~4.5 us dispatches).
+struct IvfPrepArgs {
+    EpsArgs eps;                  // (eps.info is replaced by the workgroup's copy)
+    const float *Q;
+    int64_t nq;
+    int D, Dpad;
+    _Float16 *qrows;
+    signed char *q8;              // nullptr: no int8 list scan offered
+    QueryBatchInfo *info;         // this index's batch info (published when from_src)
+    const QueryBatchInfo *src;    // statistics of the same queries taken by the coarse index, or nullptr (info is final)
+    FinalizeArgs fin;
+    unsigned n_eps_blocks;
+};
+__global__ __launch_bounds__(256) void ivf_prep_kernel(IvfPrepArgs a) {
+    __shared__ QueryBatchInfo s_info;
+    const QueryBatchInfo *info = a.info;
+    if (a.src) {
+        if (threadIdx.x == 0) {
+            s_info = *a.src;
+            query_finalize_values(&s_info, a.fin, __uint_as_float(s_info.absmax_bits), s_info.not_integer, s_info.nonfinite,
+                                  s_info.not_u8, s_info.not_s8);
+            if (blockIdx.x == 0) *a.info = s_info;
+        }
+        __syncthreads();
+        info = &s_info;
+    }
+    if (blockIdx.x < a.n_eps_blocks) {
+        EpsArgs e = a.eps;
+        e.info = info;
+        query_eps_body((int64_t)blockIdx.x * 256 + threadIdx.x, e);
+        return;
+    }
+    const int64_t i = (int64_t)(blockIdx.x - a.n_eps_blocks) * 256 + threadIdx.x;
+    if (i >= a.nq * a.Dpad) return;
+    const int64_t q = i / a.Dpad;
+    const int d = (int)(i - q * a.Dpad);
     const int mode = info->i8_mode;
-    if (mode && q8) {
+    if (mode && a.q8) {
         const int cq = (mode & 3) == 1 ? 127 : -1;
-        q8[i] = (signed char)(d < D ? cq - (int)Q[(size_t)q * D + d] : 0);
+        a.q8[i] = (signed char)(d < a.D ? cq - (int)a.Q[(size_t)q * a.D + d] : 0);
     } else {
-        qrows[i] = (_Float16)(d < D ? Q[(size_t)q * D + d] * info->bscale : 0.f);
+        a.qrows[i] = (_Float16)(d < a.D ? a.Q[(size_t)q * a.D + d] * info->bscale : 0.f);
     }
 }
 

@@ -148,12 +148,19 @@ struct FinalizeArgs {
     int corpus_i8;             // 0 = fp16 scan only; else the index holds an int8 scan copy this search may use: 1 = select on
                                // quads, 5 = on octs (bit 2 is copied into QueryBatchInfo.i8_mode)
 };
+// scales from the five statistics already present in *info (any address space: the caller has made them visible)
+__device__ inline void query_finalize_values(QueryBatchInfo *info, const FinalizeArgs &f, float amax, int not_integer,
+                                             int nonfinite, int not_u8, int not_s8);
 __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &f) {
     const float amax = __uint_as_float(__hip_atomic_load(&info->absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int not_integer = __hip_atomic_load(&info->not_integer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nonfinite = __hip_atomic_load(&info->nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int not_u8 = __hip_atomic_load(&info->not_u8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int not_s8 = __hip_atomic_load(&info->not_s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    query_finalize_values(info, f, amax, not_integer, nonfinite, not_u8, not_s8);
+}
+__device__ inline void query_finalize_values(QueryBatchInfo *info, const FinalizeArgs &f, float amax, int not_integer,
+                                             int nonfinite, int not_u8, int not_s8) {
     const float fm = (f.metric == 0) ? 2.f : 1.f;
     float sq = 1.f;
     const bool int_ok = f.corpus_int_unscaled && !not_integer && fm * amax <= 2048.f;
@@ -172,18 +179,6 @@ __device__ inline void query_finalize(QueryBatchInfo *info, const FinalizeArgs &
         const int window = !not_u8 ? 1 : (!not_s8 ? 2 : 0);
         info->i8_mode = window ? (window | (f.corpus_i8 & 4)) : 0;
     }
-}
-
-// One thread: scales of a batch whose statistics were already taken by another index on the SAME queries (the coarse
-// quantizer of an IVF index scans the batch first): copy the five statistics, finalise with this index's scales.
-__global__ void query_finalize_from_kernel(QueryBatchInfo *info, const QueryBatchInfo *src, FinalizeArgs fin) {
-    info->absmax_bits = src->absmax_bits;
-    info->not_integer = src->not_integer;
-    info->nonfinite = src->nonfinite;
-    info->not_u8 = src->not_u8;
-    info->not_s8 = src->not_s8;
-    __threadfence_block();
-    query_finalize(info, fin);
 }
 
 // Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics + fence per workgroup
