@@ -229,14 +229,48 @@ __global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_
     // distance from below, hence a row scoring below tau - 2 eps is among the k nearest for certain and is written out
     // as it is; only the band around tau is re-scored in float64, and its best k - #certain rows complete the set.
     int ncert = 0;
-    if (a.set_only && a.D && ncand > k) {
-        unsigned t2 = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned trial = t2 | ((1u << bit) - 1u);
-            int cnt = 0;
-            for (int base = 0; base < ncand; base += 64)
-                cnt += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= trial));
-            if (cnt < k) t2 |= (1u << bit);
+    if (a.set_only && a.D && ncand >= k) {
+        unsigned t2 = 0xFFFFFFFFu;
+        bool decided = ncand == k;     // exactly k rows within tau + 2 eps: every other row is farther than each of them
+        if (!decided) {
+            t2 = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned trial = t2 | ((1u << bit) - 1u);
+                int cnt = 0;
+                for (int base = 0; base < ncand; base += 64)
+                    cnt += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= trial));
+                if (cnt < k) t2 |= (1u << bit);
+            }
+            // A gap wider than 2 eps between the k-th and the (k+1)-th approximate score settles the SET without any exact
+            // re-scoring (exact_i <= tau + eps < next - eps <= exact_j; rows outside the candidate list are farther still) --
+            // the usual case for a coarse quantizer, and the float64 keys were a third of this kernel's vector work.
+            int cnt_le = 0;
+            unsigned next = 0xFFFFFFFFu;
+            for (int base = 0; base < ncand; base += 64) {
+                const bool valid = base + lane < ncand;
+                const unsigned ck = valid ? ckeys[base + lane] : 0xFFFFFFFFu;
+                cnt_le += __popcll(__ballot(valid && ck <= t2));
+                if (ck > t2) next = min(next, ck);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) next = min(next, (unsigned)__shfl_xor((int)next, o));
+            const float tau0 = unsortable_f32(t2);
+            decided = cnt_le == k && next != 0xFFFFFFFFu && unsortable_f32(next) - tau0 > e2 + 2.0e-6f * fabsf(tau0);
+        }
+        if (decided) {
+            int nout = 0;
+            for (int base = 0; base < ncand; base += 64) {
+                const int i = base + lane;
+                const bool in = i < ncand && ckeys[i] <= t2;
+                const unsigned long long m = __ballot(in);
+                if (in) a.I[(size_t)q * k + nout + __popcll(m & lt_mask)] = a.c.id_base + cands[i];
+                nout += __popcll(m);
+            }
+            if (lane == 0) {
+                a.fallback[q] = 0;
+                stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
+            }
+            return;
         }
         const float tau = unsortable_f32(t2);
         const unsigned ckey = sortable_u32(tau - e2 - 1.0e-6f * fabsf(tau));   // (lowered a little more: rounding of the subtraction)
