@@ -182,10 +182,10 @@ __device__ inline void query_finalize_values(QueryBatchInfo *info, const Finaliz
 }
 
 // Launch with query_stats_blocks(total) workgroups: few enough that the one set of atomics + fence per workgroup
-// (same addresses for everybody) stays a few dozen operations -- 1250 workgroups cost 21 us on a 5 MB batch, the
-// read itself takes 1-2.
+// (same addresses for everybody) stays a few dozen operations -- on a 5 MB batch 1250 workgroups cost 21 us, 313 cost
+// 15, 79 cost 10 and 40 cost 12 (then the reads of a thread queue up); the read itself takes 1-2.
 inline unsigned query_stats_blocks(int64_t total) {
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 512));
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 16383) / 16384, 256));
 }
 __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restrict__ Q, int64_t total,
                                                           QueryBatchInfo *info, FinalizeArgs fin) {
