@@ -80,6 +80,9 @@ struct IvfPlan {          // device-resident scalars written by ivf_plan_kernel
 constexpr int kIvfLdsLists = 8192;
 constexpr int kIvfPairsPerBlock = 4096;
 
+// PPB: (query, probe) pairs per workgroup -- kIvfPairsPerBlock for large batches (fewer global atomics per list), a
+// quarter of it when that would leave most CUs idle (80 000 pairs = 20 workgroups).
+template <int PPB>
 __global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restrict__ probes, int64_t n, int nlist,
                                                         int32_t *__restrict__ cnt) {
     extern __shared__ int ivf_hist[];
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restric
         for (int l = threadIdx.x; l < nlist; l += 256) ivf_hist[l] = 0;
         __syncthreads();
     }
-    const int64_t i0 = (int64_t)blockIdx.x * kIvfPairsPerBlock;
-    for (int j = threadIdx.x; j < kIvfPairsPerBlock; j += 256) {
+    const int64_t i0 = (int64_t)blockIdx.x * PPB;
+    for (int j = threadIdx.x; j < PPB; j += 256) {
         const int64_t i = i0 + j;
         if (i >= n) break;
         const int64_t l = probes[i];
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
 
 // slot of every (query, probe): workgroup-local rank from an LDS histogram + one global cursor bump per
 // (workgroup, touched list).  Slot order inside a list is arbitrary (results do not depend on it).
+template <int PPB>
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
                                                           int nlist, const int32_t *__restrict__ slot_off,
                                                           const int32_t *__restrict__ list_pspan0,
@@ -192,13 +196,13 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restr
     extern __shared__ int ivf_hist[];   // [nlist] local counts, then global bases
     const bool use_lds = nlist <= kIvfLdsLists;
     const int64_t n = nq * nprobe;
-    const int64_t i0 = (int64_t)blockIdx.x * kIvfPairsPerBlock;
+    const int64_t i0 = (int64_t)blockIdx.x * PPB;
     const bool dead = plan->overflow != 0;
     if (use_lds) {
         for (int l = threadIdx.x; l < nlist; l += 256) ivf_hist[l] = 0;
         __syncthreads();
     }
-    constexpr int PER = kIvfPairsPerBlock / 256;
+    constexpr int PER = PPB / 256;
     int rank[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
