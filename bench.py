@@ -76,9 +76,11 @@ def device_rows(n: int, d: int, rank: int, dev):
     return X
 
 
-def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32) -> float:
+def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32, dist=None, world: int = 1) -> float:
     """Recall of the first `sample` queries against a float64 torch scan of the device-resident corpus (used for
-    workloads too large to hand to the CPU oracle)."""
+    workloads too large to hand to the CPU oracle).  With world > 1 every rank scans ITS shard, the per-shard exact
+    top-k (scores + global ids) are all-gathered and merged, and the merged list is what the result is compared with
+    (the result holds neighbours from every shard)."""
     import torch
 
     q = q_t[:sample].double()
@@ -94,6 +96,14 @@ def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int =
             cv, ci = torch.cat([best_v, v], 1), torch.cat([best_i, i], 1)
             best_v, sel = torch.topk(cv, k, dim=1)
             best_i = torch.gather(ci, 1, sel)
+    if dist is not None and world > 1:
+        vs = [torch.empty_like(best_v) for _ in range(world)]
+        ids = [torch.empty_like(best_i) for _ in range(world)]
+        dist.all_gather(vs, best_v.contiguous())
+        dist.all_gather(ids, best_i.contiguous())
+        cv, ci = torch.cat(vs, 1), torch.cat(ids, 1)
+        best_v, sel = torch.topk(cv, k, dim=1)
+        best_i = torch.gather(ci, 1, sel)
     got = I_t[:sample].cpu().numpy()
     ref = best_i.cpu().numpy()
     return float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(ref, got)]))
@@ -555,7 +565,8 @@ def main() -> int:
                                    "sample": f"first {sample} of {nq} queries, nprobe {args.nprobe}, {dt:.1f} s"}
             out["ids_equal_cpu_oracle_sample"] = bool(np.array_equal(io_, gpu_ids[:sample]))
     if X is None:
-        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, rank * n), 6)
+        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, rank * n, dist=dist,
+                                                                       world=world), 6)
     elif rank == 0 and world == 1 and not ivf:
         if workload == "sift1m" and not args.no_extras:
             # second timed workload of the same run: Gaussian 1M (corpus NOT exact in fp16 -> non-trivial guard)

@@ -256,3 +256,44 @@ def test_golden_manifest_holds_the_published_ivf_point(golden_dir):
     pub = json.loads((golden_dir / "manifest.json").read_text())["published_points"]["random_ivf_flat"]
     assert pub["ivf_flat"]["recall@10"] == 0.410546875 and pub["exact"]["recall@10"] == 1.0
     assert pub["index_type"] == "IVF100,Flat" and pub["nprobe"] == 10 and pub["config_seed"] == 42
+
+
+def test_bench_recall_check_merges_the_shards_exact_lists():
+    """bench.py's float64 recall check under N > 1: the result holds neighbours from every shard, so every rank's exact
+    per-shard top-k is all-gathered and merged before the comparison (with a one-shard reference the recall of a
+    correct 8-rank result would read 1/8).  Run on CPU tensors with a stand-in for torch.distributed."""
+    import torch
+
+    import bench
+
+    rng = np.random.default_rng(5)
+    X = torch.from_numpy(rng.standard_normal((4000, 24)).astype(np.float32))
+    Q = torch.from_numpy(rng.standard_normal((32, 24)).astype(np.float32))
+    k = 10
+    s = Q.double() @ X.double().T
+    I_true = torch.topk(s, k, dim=1).indices                       # exact result over BOTH shards, global ids
+
+    class Recorder:                                                # captures what a rank would contribute
+        def __init__(self):
+            self.sent = []
+
+        def all_gather(self, lst, t):
+            self.sent.append(t.clone())
+            for x in lst:
+                x.copy_(t)
+
+    rec = Recorder()
+    bench.device_check(X[2000:], Q, I_true, k, "ip", 2000, dist=rec, world=2)
+    other_v, other_i = rec.sent
+
+    class Rank0:                                                   # rank 0's view of a two-rank all_gather
+        def __init__(self):
+            self.calls = 0
+
+        def all_gather(self, lst, t):
+            lst[0].copy_(t)
+            lst[1].copy_(other_v if self.calls == 0 else other_i)
+            self.calls += 1
+
+    assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0, dist=Rank0(), world=2) == 1.0
+    assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0) < 0.9      # (one shard alone cannot explain the merged result)
