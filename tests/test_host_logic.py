@@ -297,3 +297,29 @@ def test_bench_recall_check_merges_the_shards_exact_lists():
 
     assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0, dist=Rank0(), world=2) == 1.0
     assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0) < 0.9      # (one shard alone cannot explain the merged result)
+
+
+def test_batch_result_shape_contract():
+    """what the harness accepts from batch_search and what it hands to recall_at_k."""
+    from vdbhip.harness import normalize_batch_indices as norm
+
+    ids = np.arange(12, dtype=np.int32).reshape(3, 4)
+    got = norm((np.zeros((3, 4)), ids), 3, 4)                      # (distances, indices) pair, exact width
+    assert got.dtype == np.int64 and np.array_equal(got, ids)
+    assert np.array_equal(norm(ids, 3, 2), ids[:, :2])             # wider than k: cut
+    wide = norm(ids, 3, 6)                                         # narrower than k: filled with -1
+    assert np.array_equal(wide[:, :4], ids) and (wide[:, 4:] == -1).all()
+    ragged = norm([[5, 6, 7], [1], [], [9, 9, 9]], 3, 2)           # list rows, ragged, surplus row ignored
+    assert ragged.tolist() == [[5, 6], [1, -1], [-1, -1]]
+    short = norm([[4, 2]], 2, 2)                                   # fewer list rows than queries
+    assert short.tolist() == [[4, 2], [-1, -1]]
+    assert norm(np.array([3, 1, 2]), 1, 3).tolist() == [[3, 1, 2]]          # flat answer to one query
+    assert norm(np.array([[3], [1], [2]]), 1, 3).tolist() == [[3, 1, 2]]    # (k, 1) column for one query
+    assert norm(np.array([[7]]), 1, 1).tolist() == [[7]]
+    assert norm(np.array([2.0, 1.0]), 1, 2).dtype == np.int64
+    with pytest.raises(ValueError, match=r"must return \(distances, indices\)"):
+        norm((ids, ids, ids), 3, 4)
+    with pytest.raises(ValueError, match="unexpected shape"):
+        norm(np.zeros((2, 2, 2)), 2, 2)
+    with pytest.raises(ValueError, match="returned 3 rows, expected 2"):
+        norm(ids, 2, 4)
