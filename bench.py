@@ -1,29 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- QPS of the exact k-NN hot path on MI355X (BASELINE.json metric).
+"""bench.py -- QPS of the exact / IVF-Flat k-NN hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--nprobe P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--nprobe P] [--scaling weak|strong]
 
-A "step" is one pass of the hot path over one 10 000-query batch already resident in HBM:
-libvdbhip's device pipeline (query prep -> MFMA scan + bin select -> exact float64 refine), and for
-N > 1 the RCCL all-gather of the per-shard partial top-k plus the merge kernel.
+A "step" is one pass of the hot path over one 10 000-query batch already resident in HBM: libvdbhip's device
+pipeline (query prep -> MFMA scan + bin select -> exact refine), and for N > 1 the RCCL all-gather of the per-shard
+partial top-k plus the merge kernel.
 
-N = 1   default workload = BASELINE.json configs[1]: SIFT1M-shaped corpus (1 000 000 x 128, integer-valued float32),
-        10 000 queries, k = 10, L2.  Synthetic unless real SIFT1M files are found under $VDBHIP_DATA
-        (sift_base.fvecs / sift_query.fvecs / sift_groundtruth.ivecs, read with vdbhip.io's correct reader).
+N = 1   headline = BASELINE.json configs[1]: SIFT1M-shaped corpus (1 000 000 x 128, byte-valued float32), 10 000
+        queries, k = 10, L2 (real SIFT1M files under $VDBHIP_DATA are used when present).  `value` is the
+        device-resident rate the bench contract asks for; `value_host_io` beside it is what the reference harness
+        measures (wall clock of `batch_search` with NumPy queries in and NumPy (D, I) out,
+        experiment_runner.py:428-439, 464).  The SAME line carries every other single-GPU BASELINE config as
+        `also.*`, each with its own `roofline`, recall and `cpu_baseline`:
+          also.gaussian1m   configs[1] shape on data that is NOT exact in fp16 (fp16 MFMA scan + error-bound guard)
+          also["glove1.2m"] configs[2]: 1.2M x 50, inner product
+          also.ivf1024      configs[3]: IVF-Flat nlist = 1024 over the sift1m data, ONE index trained by the library's
+                            own k-means, nprobe 8 / 32 / 128
+          also.msmarco_ivf  the reference's committed IVF-on-embeddings shape (100 000 x 384, cosine, IVF100,Flat,
+                            nprobe 32, k = 20: benchmark_results/.../msmarco/ivf_flat_results.json) on the K-loop list scan
+          also.serving      1 / 64-query batches: latency + the HBM roofline of the scan, on the Infinity-Cache-resident
+                            1M x 128 copy (labelled so) and on a 4M x 128 copy (also.serving.bytes4m, 512 MB > 256 MiB: a true HBM number)
+          also["marco12.5m"] configs[4] per-GPU shard, the N = 1 point of the N > 1 series
 N > 1   default workload = BASELINE.json configs[4] per-GPU shard: 12.5M x 768 inner product, rows generated on
-        device (block seeds by global block number).  One process per GPU (torch.distributed, backend nccl = RCCL);
-        launched by the driver's torchrun line, or by this script itself: with --gpus N > 1 and no WORLD_SIZE in the
-        environment the parent process (which never touches a GPU) starts N ranks and relays rank 0's line.
+        device (block seeds by GLOBAL block number: the corpus does not depend on N).  One process per GPU
+        (torch.distributed, backend nccl = RCCL); launched by the driver's torchrun line, or by this script itself.
+        --scaling weak (default): every rank holds 12.5M rows (100M at N = 8); `value` = (query x shard) scans / s.
+        --scaling strong: the 12.5M-row corpus is SPLIT over the N ranks (same rows, same queries, same result for
+        every N: `result_checksum`); `value` = queries / s against the whole corpus.
         Every rank scans ITS shard for the SAME 10 000-query batch; partial (key64, id) lists are all-gathered and
-        merged on every rank.  Weak scaling (the corpus grows with N: N x 12.5M rows, 100M at N = 8); `value` counts
-        the (query x shard) scans all ranks complete per second; `qps_whole_corpus` is queries/s against the N-shard
-        corpus.
+        merged on every rank; `exchange_ms` times that all-gather + merge alone.
 
-Output: ONE JSON line on rank 0 carrying `roofline` (dominant kernel, MFMA-bound, algorithmic flops 2*Q*N*D per
-launch over the HIP-event time recorded on the search stream during the timed steps), and at N = 1 `cpu_baseline`
-(threaded-BLAS GEMM expansion; `cpu_baselines` also holds the C port and the NumPy LinearSearcher
-restatement), `qps_plugin_host_io` + `first_call_ms` (the reference harness's view: HipExactSearch.batch_search with
-pageable NumPy in/out, experiment_runner.py:431-437) and `also.gaussian1m` (the non-fp16-exact case, same run).
+Output: ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -33,6 +41,7 @@ import os
 import subprocess
 import sys
 import time
+import zlib
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
@@ -55,25 +64,66 @@ WORKLOADS = {
     # blocks seeded by the global block number, so the data do not depend on the number of ranks
     "marco12.5m": (12_500_000, 768, 10_000, 10, "ip", "device_gaussian"),
     "gauss50m": (50_000_000, 128, 10_000, 10, "l2", "device_gaussian"),     # capacity check of the flat D <= 128 path
+    "bytes4m": (4_000_000, 128, 64, 10, "l2", "device_bytes"),              # serving leg: scan copy > Infinity Cache
     "smoke": (10_000, 128, 100, 10, "l2", "random_reference"),
     # BASELINE configs[3]: IVF-Flat over the sift1m data, nlist = 1024, --nprobe 8 / 32 / 128
     "ivf1024": (1_000_000, 128, 10_000, 10, "l2", "sift_like"),
+    # the reference's committed IVF-on-embeddings benchmark shape (msmarco subset): cosine = normalise + ip
+    "msmarco_ivf": (100_000, 384, 10_000, 20, "ip", "unit_gaussian"),
 }
 DEVICE_BLOCK_ROWS = 500_000
 
 
-def device_rows(n: int, d: int, rank: int, dev):
-    """(n, d) float32 standard-normal rows generated on `dev`, block b of the whole corpus from seed 1234 + b."""
+def usable_cpus() -> int:
+    """CPUs this process may use: the affinity mask, cut to the cgroup quota when there is one (a GPU box gives one
+    GPU's share of a 256-thread host).  EVERY CPU leg runs on exactly this many threads and reports it as `cores`."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+def device_rows_range(lo: int, hi: int, d: int, dev):
+    """Rows [lo, hi) of the device-generated corpus: block b = rows [b * 500k, (b + 1) * 500k) from seed 1234 + b."""
     import torch
 
-    X = torch.empty((n, d), dtype=torch.float32, device=dev)
+    X = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
     gen = torch.Generator(device=dev)
-    blocks_per_rank = -(-n // DEVICE_BLOCK_ROWS)
-    for b in range(blocks_per_rank):
-        lo, hi = b * DEVICE_BLOCK_ROWS, min(n, (b + 1) * DEVICE_BLOCK_ROWS)
-        gen.manual_seed(1234 + rank * blocks_per_rank + b)
-        X[lo:hi].normal_(generator=gen)
+    for b in range(lo // DEVICE_BLOCK_ROWS, -(-hi // DEVICE_BLOCK_ROWS)):
+        b0, b1 = b * DEVICE_BLOCK_ROWS, (b + 1) * DEVICE_BLOCK_ROWS
+        gen.manual_seed(1234 + b)
+        if b0 >= lo and b1 <= hi:
+            X[b0 - lo:b1 - lo].normal_(generator=gen)
+        else:            # a rank boundary inside the block: generate the whole block, keep the overlap
+            tmp = torch.empty((DEVICE_BLOCK_ROWS, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+            s0, s1 = max(lo, b0), min(hi, b1)
+            X[s0 - lo:s1 - lo] = tmp[s0 - b0:s1 - b0]
+            del tmp
     return X
+
+
+def device_byte_rows(n: int, d: int, dev, seed: int):
+    """(n, d) float32 rows of integers 0..218, exponentially skewed like SIFT descriptors, generated on the device (the
+    host generator of the sift1m rows needs 10 s per million)."""
+    import torch
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    X = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for lo in range(0, n, 1_000_000):
+        X[lo:lo + 1_000_000].exponential_(1.0 / 28.0, generator=gen)
+    return X.round_().clamp_(0.0, 218.0)
+
+
+def device_rows(n: int, d: int, rank: int, dev):
+    """(n, d) float32 standard-normal rows of rank `rank` under weak scaling: global rows [rank * n, (rank + 1) * n)."""
+    blocks = -(-n // DEVICE_BLOCK_ROWS)
+    base = rank * blocks * DEVICE_BLOCK_ROWS
+    return device_rows_range(base, base + n, d, dev)
 
 
 def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32, dist=None, world: int = 1) -> float:
@@ -141,6 +191,14 @@ def make_data(name: str, rank: int):
     elif gen == "glove_like":
         X = 0.5 * np.random.default_rng(50 + 7919 * rank).standard_normal((n, d), dtype=np.float32)
         Q = 0.5 * np.random.default_rng(51).standard_normal((nq, d), dtype=np.float32)
+    elif gen == "unit_gaussian":     # sentence-embedding shaped: a few dozen loose clusters on the unit sphere
+        rng = np.random.default_rng(384 + 7919 * rank)
+        centres = rng.standard_normal((64, d), dtype=np.float32)
+        X = centres[rng.integers(0, 64, n)] + 1.5 * rng.standard_normal((n, d), dtype=np.float32)
+        rq = np.random.default_rng(385)
+        Q = centres[rq.integers(0, 64, nq)] + 1.5 * rq.standard_normal((nq, d), dtype=np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
     else:
         X, Q = datasets.random_reference(d, n, nq, 42)
     return np.ascontiguousarray(X, np.float32), np.ascontiguousarray(Q, np.float32), k, metric
@@ -150,32 +208,41 @@ def recall_vs(ids_ref, ids_got, k) -> float:
     return float(np.mean([len(set(a[:k].tolist()) & set(b[:k].tolist())) / k for a, b in zip(ids_ref, ids_got)]))
 
 
-def cpu_baselines(X, Q, k, metric, gpu_ids):
-    """SURVEY 8(d) CPU legs on this box's host cores, each on a bounded query sample of the same workload; the ids of
-    the BLAS leg double as a recall check of the GPU result."""
-    from oracle import blas_baseline, c_oracle
+def blas_leg(X, Q, k, metric, budget_s):
+    """Threaded-BLAS GEMM expansion with BLAS and select threads both limited to usable_cpus()."""
+    from oracle import blas_baseline
 
-    out = {}
-    blas, ids = blas_baseline.time_gemm_expansion(X, Q, k, metric, budget_s=10.0)
-    out["blas_gemm_expansion"] = blas
-    recall = recall_vs(ids, gpu_ids[:len(ids)], k)
-    # the hand-written C port (scalar / omp simd dot loops, no BLAS), all host threads
+    cpus = usable_cpus()
+    try:
+        from threadpoolctl import threadpool_limits
+
+        ctx = threadpool_limits(limits=cpus, user_api="blas")
+    except Exception:  # noqa: BLE001
+        import contextlib
+
+        ctx = contextlib.nullcontext()
+    with ctx:
+        leg, ids = blas_baseline.time_gemm_expansion(X, Q, k, metric, budget_s=budget_s, threads=cpus)
+    return leg, ids
+
+
+def c_port_leg(X, Q, k, metric, budget_s):
+    """The hand-written C port (scalar / omp simd dot loops, no BLAS) on usable_cpus() OpenMP threads."""
+    from oracle import c_oracle
+
     c_oracle.build()
-    cores = c_oracle.num_threads()
+    cores = usable_cpus()
     probe = min(len(Q), 4 * cores)
     t0 = time.perf_counter()
-    c_oracle.knn(X, Q[:probe], k, metric, mode=c_oracle.MODE_GEMM32)
+    c_oracle.knn(X, Q[:probe], k, metric, mode=c_oracle.MODE_GEMM32, threads=cores)
     dt = time.perf_counter() - t0
-    sample = int(min(len(Q), max(probe, probe * 6.0 / max(dt, 1e-6))))
+    sample = int(min(len(Q), max(probe, probe * budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter()
-    c_oracle.knn(X, Q[:sample], k, metric, mode=c_oracle.MODE_GEMM32)
+    c_oracle.knn(X, Q[:sample], k, metric, mode=c_oracle.MODE_GEMM32, threads=cores)
     dt = time.perf_counter() - t0
-    out["c_port"] = {"value": round(sample / dt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-                     "impl": "oracle/knn_oracle.c MODE_GEMM32 (float32 expansion, OpenMP, no BLAS)",
-                     "sample": f"first {sample} of {len(Q)} queries against all {len(X)} rows, {dt:.1f} s"}
-    if metric == "l2":   # the reference's own CPU path for YAML `exact` (NumPy LinearSearcher), tiny query batches
-        out["numpy_linear_searcher"] = blas_baseline.time_linear_searcher(X, Q, k, metric, qbatch=4, budget_s=5.0)
-    return out, recall
+    return {"value": round(sample / dt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "impl": f"oracle/knn_oracle.c MODE_GEMM32 (float32 expansion, OpenMP on {cores} threads, no BLAS)",
+            "sample": f"first {sample} of {len(Q)} queries against all {len(X)} rows, {dt:.1f} s"}
 
 
 def timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch):
@@ -193,16 +260,189 @@ def timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch)
     return elapsed, st
 
 
+def host_io_timing(algo, Q, k, first=True):
+    """The reference harness's view (experiment_runner.py:330, 428-439, 464): batch_search timed with time.time(),
+    pageable NumPy queries in, NumPy (D, I) out; the very first call after build_index, then the median of 11."""
+    out = {}
+    if first:
+        t1 = time.time()
+        algo.batch_search(Q, k=k)
+        out["first_call_ms"] = round((time.time() - t1) * 1e3, 3)
+    for _ in range(3):
+        algo.batch_search(Q, k=k)
+    times = []
+    for _ in range(11):
+        t1 = time.time()
+        algo.batch_search(Q, k=k)
+        times.append(time.time() - t1)
+    med = float(np.median(times))
+    out["value_host_io"] = round(len(Q) / med, 1)
+    out["host_io_ms"] = round(med * 1e3, 4)
+    return out
+
+
+HOST_IO_NOTE = ("value_host_io = SURVEY 8(d): wall clock of <plugin>.batch_search(Q pageable numpy) -> numpy (D, I), H2D of Q "
+                "and D2H of the result inside the timed call (experiment_runner.py:428-439), median of 11 after 3 "
+                "warm-ups; first_call_ms = the very first call after build_index (the reference has no warm-up; "
+                "build_index sizes the workspace for 10 000 queries: vdb_reserve); `value` = the same batch with the "
+                "queries and the result resident in HBM, K steps between two synchronisations")
+
+
+def pipeline_of(st, nq, build_s, corpus_bytes):
+    res = float(st["bytes_resident"])
+    return {"path": st["last_path_name"], "candidates_per_query": round(st["last_candidates"] / nq, 2),
+            "rescan_bins": int(st["last_rescan_bins"]), "fallback_queries": int(st["last_fallback_queries"]),
+            "corpus_fp16_exact": int(st["corpus_fp16_exact"]), "build_s": round(build_s, 3),
+            "hbm_resident_mb": round(res / 2 ** 20, 1), "corpus_mb": round(corpus_bytes / 2 ** 20, 1),
+            "hbm_resident_over_corpus": round(res / max(corpus_bytes, 1), 3)}
+
+
+def scan_dtype_name(st) -> str:
+    return ("i8 MFMA scan (i32 accumulate) + exact integer / f64 refine" if int(st.get("scan_dtype", 0)) == 1
+            else "f16 MFMA scan (f32 accumulate) + f64 exact refine")
+
+
+def flat_leg(vdbhip, torch, name, dev, local_rank, stream, steps, warmup, cpu_budget_s=6.0, host_io=True,
+             data=None, keep_index=False, all_cpu_legs=False):
+    """One brute-force workload through the plugin: build, host-I/O timing, device-resident timed loop with the scan's
+    HIP-event roofline, recall against a CPU leg on a bounded query sample."""
+    n, d = WORKLOADS[name][:2]
+    X, Q, k, metric = data if data is not None else make_data(name, 0)
+    n, d = X.shape
+    nq = Q.shape[0]
+    t0 = time.perf_counter()
+    algo = vdbhip.get_algorithm_instance("HipExactSearch", d, name="bench", metric=metric, device=local_rank)
+    algo.build_index(X)
+    build_s = time.perf_counter() - t0
+    leg = {}
+    if host_io:
+        leg.update(host_io_timing(algo, Q, k))
+    index = algo.index
+    q_t = torch.from_numpy(Q).to(dev)
+    D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    el, st = timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch)
+    ids = I_t.cpu().numpy()
+    out = {"value": round(nq * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
+           "config": f"{name}: {n} rows x {d} dims, {nq} queries, k={k}, {metric}; brute-force exact k-NN",
+           "dtype": scan_dtype_name(st)}
+    out.update(leg)
+    out["roofline"] = roofline_of(st, nq, n, d, name)
+    out["pipeline"] = pipeline_of(st, nq, build_s, X.nbytes)
+    if cpu_budget_s > 0:
+        bl, bids = blas_leg(X, Q, k, metric, cpu_budget_s)
+        out["cpu_baseline"] = bl
+        out["recall@10_vs_cpu_blas_sample"] = round(recall_vs(bids, ids[:len(bids)], k), 6)
+        if all_cpu_legs:
+            from oracle import blas_baseline
+
+            legs = {"blas_gemm_expansion": bl, "c_port": c_port_leg(X, Q, k, metric, cpu_budget_s * 0.6)}
+            if metric == "l2":   # the reference's own CPU path for YAML `exact` (NumPy LinearSearcher), tiny query batches
+                legs["numpy_linear_searcher"] = blas_baseline.time_linear_searcher(X, Q, k, metric, qbatch=4, budget_s=4.0)
+            out["cpu_baselines"] = legs
+        from oracle import c_oracle
+
+        _, io_ = c_oracle.knn(X, Q[:32], k, metric, threads=usable_cpus())
+        out["ids_equal_cpu_oracle_first32"] = bool(np.array_equal(ids[:32], io_))
+    if keep_index:
+        return out, (algo, index, q_t, D_t, I_t, X, Q, ids)
+    index.close()
+    return out
+
+
+def ivf_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup, nprobes, name="ivf1024", nlist=1024, data=None,
+            cpu_budget_s=5.0, plugin_metric=None):
+    """BASELINE configs[3]: ONE IVF-Flat index (the library's own k-means: vdb_ivf_train 25 iterations, seed 1234),
+    `set_nprobe` per point; each point with the list scan's roofline, recall@10 against the exact result of the same
+    queries, and the C restatement of the same search (same centroids, same lists) as the CPU leg and bit-level check."""
+    from oracle import c_oracle
+
+    X, Q, k, metric = data if data is not None else make_data(name, 0)
+    n, d = X.shape
+    nq = Q.shape[0]
+    t0 = time.perf_counter()
+    index = vdbhip.IVFFlatIndex(d, nlist, metric, local_rank)
+    index.train(X, niter=25, seed=1234, max_points_per_centroid=256)
+    train_s = time.perf_counter() - t0
+    index.add(X)
+    build_s = time.perf_counter() - t0
+    flat = vdbhip.FlatIndex(d, metric, local_rank)
+    flat.add(X)
+    _, exact_ids = flat.search(Q, k)
+    flat.close()
+    C, lor = index.centroids(), index.assignment()
+    sizes = np.bincount(lor, minlength=nlist)
+    q_t = torch.from_numpy(Q).to(dev)
+    D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    c_oracle.build()
+    cores = usable_cpus()
+    out = {"config": f"{name}: {n} rows x {d} dims, {nq} queries, k={k}, {metric}; IVF-Flat nlist={nlist}, own k-means "
+                     f"(25 iterations on {min(n, 256 * nlist)} sampled rows)",
+           "train_s": round(train_s, 3), "build_s": round(build_s, 3),
+           "list_rows": {"min": int(sizes.min()), "median": int(np.median(sizes)), "max": int(sizes.max())}}
+    for p in nprobes:
+        index.set_nprobe(p)
+        host = {}
+        for _ in range(2):
+            index.search(Q, k)
+        ts = []
+        for _ in range(7):
+            t1 = time.time()
+            index.search(Q, k)
+            ts.append(time.time() - t1)
+        host["value_host_io"] = round(nq / float(np.median(ts)), 1)
+        el, st = timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch)
+        ids = I_t.cpu().numpy()
+        rows_probed = float(st.get("last_rows_scanned", 0)) or nq * p / float(nlist) * n
+        roof = roofline_of(st, nq, n, d, name, ivf_rows_probed=rows_probed)
+        roof["hbm_equiv"] = {"bound": "hbm", "achieved": round(4.0 * d * rows_probed / (roof["kernel_ms"] * 1e-3) / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "note": "SURVEY 8(d): 4*D bytes x (query, row) pairs / scan time -- what a per-query list "
+                                     "scan would have to stream; the list-major scan reads a list once per query group"}
+        point = {"value": round(nq * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
+                 "dtype": scan_dtype_name(st), **host, "roofline": roof,
+                 "recall@10_vs_exact": round(recall_vs(exact_ids, ids, min(k, 10)), 6),
+                 "pipeline": {"path": st["last_path_name"], "candidates_per_query": round(st["last_candidates"] / nq, 2),
+                              "rescan_bins": int(st["last_rescan_bins"]),
+                              "fallback_queries": int(st["last_fallback_queries"]),
+                              "rows_scanned_per_query": round(rows_probed / nq, 1),
+                              "hbm_resident_mb": round(st["bytes_resident"] / 2 ** 20, 1)}}
+        if k != 10:
+            point[f"recall@{k}_vs_exact"] = round(recall_vs(exact_ids, ids, k), 6)
+        if cpu_budget_s > 0:
+            probe = min(nq, 128)
+            t1 = time.perf_counter()
+            c_oracle.ivf_search(X, C, lor, Q[:probe], k, p, metric, threads=cores)
+            dt = time.perf_counter() - t1
+            sample = int(min(nq, max(probe, probe * cpu_budget_s / max(dt, 1e-6))))
+            t1 = time.perf_counter()
+            _, io_ = c_oracle.ivf_search(X, C, lor, Q[:sample], k, p, metric, threads=cores)
+            dt = time.perf_counter() - t1
+            point["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                                     "impl": f"oracle/ivf_oracle.c (the same IVF-Flat search: same centroids, same lists, "
+                                             f"canonical float64 list scan, OpenMP on {cores} threads); FAISS is not "
+                                             f"installed on the box",
+                                     "sample": f"first {sample} of {nq} queries, nprobe {p}, {dt:.1f} s"}
+            point["ids_equal_cpu_oracle_sample"] = bool(np.array_equal(io_, ids[:sample]))
+        out[f"nprobe{p}"] = point
+    index.close()
+    return out
+
+
 def scaling_reference_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup):
     """The N > 1 default workload (one config-5 shard, 12.5M x 768 inner product) on ONE GPU through the sharded code
     path (partial lists -> packed buffer -> merge; the all-gather of a one-rank world is a copy): the N = 1 point of
-    the weak-scaling series, in the same run as the headline."""
+    the weak- and strong-scaling series, in the same run as the headline."""
     name = "marco12.5m"
     n, d, nq, k, metric, _ = WORKLOADS[name]
     _, Q, _, _ = make_data(name, 0)
     X_t = device_rows(n, d, 0, dev)
+    t0 = time.perf_counter()
     index = vdbhip.FlatIndex(d, metric, local_rank)
     index.add_device(X_t.data_ptr(), n, id_base=0)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
     q_t = torch.from_numpy(Q).to(dev)
     D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -229,17 +469,22 @@ def scaling_reference_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup)
            "ms_per_step": round(el / steps * 1e3, 4),
            "config": f"{name}: {n} rows x {d} dims, {nq} queries, k={k}, {metric}; rows generated on device",
            "roofline": roofline_of(st, nq, n, d, name),
+           "pipeline": pipeline_of(st, nq, build_s, float(n) * d * 4),
            "recall@10_vs_float64_torch_sample": round(device_check(X_t, q_t, I_t, k, metric, 0), 6),
-           "note": "N = 1 point of the weak-scaling series: `bench.py --gpus N` (N > 1) runs this shard on every GPU "
-                   "and reports value = N x queries / time, so value(N) / (N x this value) is the scaling efficiency"}
+           "result_checksum": result_checksum(I_t),
+           "note": "N = 1 point of both N > 1 series: `bench.py --gpus N` runs this shard on every GPU (weak: value = N x "
+                   "queries / time, efficiency = value(N) / (N x this value)); `--scaling strong` splits these 12.5M rows "
+                   "over the N GPUs (speed-up = value(N) / this value, and result_checksum must not change)"}
     index.close()
     return leg
 
 
-def serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d):
-    """Serving-shaped batches on the headline index: wall time of one search_device + synchronise (median of 30) for
-    1 and 64 queries, and the HBM roofline of the scan -- a single query streams the whole scan copy once."""
+def serving_leg(vdbhip, torch, dev, local_rank, stream, index, q_t, k, n, d, tag):
+    """Serving-shaped batches: wall time of one search_device + synchronise (median of 30) for 1 and 64 queries, and the
+    HBM roofline of the scan -- a single query streams the whole scan copy once."""
     leg = {}
+    D_t = torch.empty((64, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((64, k), dtype=torch.int64, device=dev)
     for nq in (1, 64):
         for _ in range(5):
             index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
@@ -259,9 +504,8 @@ def serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d):
         scan_ms = float(st["last_scan_ms"])
         traffic, source = None, None
         try:
-            ent = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("sift1m_serving_nq1", {})
-            if i8 and n == 1_000_000 and d == 128:
-                traffic, source = ent.get("hbm_bytes_per_launch"), ent.get("source")
+            ent = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(tag + "_serving_nq1", {})
+            traffic, source = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:  # noqa: BLE001
             pass
         leg[f"nq{nq}"] = {"latency_us": round(float(np.median(ts)) * 1e6, 1), "scan_us": round(scan_ms * 1e3, 1),
@@ -272,6 +516,11 @@ def serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d):
                                        "traffic_source": (source + " -- a recorded PMC pass, not measured in this run") if source else None,
                                        "note": "rows x padded dims x %d B: the %s scan copy read once" %
                                                (1 if i8 else 2, "int8" if i8 else "fp16")}}
+    copy_mb = leg["nq1"]["roofline"]["algorithmic_bytes_per_launch"] / 2 ** 20
+    leg["scan_copy_mb"] = round(copy_mb, 1)
+    leg["residency"] = ("Infinity-Cache resident: the scan copy fits the 256 MiB MALL, repeated single-query scans need not "
+                        "touch HBM -- the GB/s here is a cache number, NOT an HBM roofline fraction" if copy_mb <= 256.0 else
+                        "HBM: the scan copy is larger than the 256 MiB Infinity Cache, every scan streams it from HBM")
     return leg
 
 
@@ -284,7 +533,10 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
     peak = PEAK_I8_TOPS if i8 else PEAK_F16_TFLOPS
     achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     if ivf_rows_probed is not None:
-        kernel = "scan_kernel<ITEMS> (list-major IVF scan)"
+        if d > 128:
+            kernel = "scan16_kloop_kernel<ITEMS> (list-major IVF scan, K-loop)"
+        else:
+            kernel = ("scan_i8_kernel" if i8 else "scan_kernel") + "<ITEMS> (list-major IVF scan)"
     elif d <= 128:
         kernel = "scan_i8_kernel" if i8 else "scan_kernel<%d>" % (4 if d <= 64 else 8)
     else:
@@ -305,32 +557,69 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
             "algorithmic_flops_per_launch": flops}
 
 
+def result_checksum(I_t) -> str:
+    """CRC32 of the (nq, k) int64 result ids: equal across N under --scaling strong (the merge is shard-count invariant)."""
+    return "%08x" % (zlib.crc32(I_t.cpu().numpy().tobytes()) & 0xFFFFFFFF)
+
+
 def launch_ranks(args) -> int:
     """--gpus N > 1 without a torchrun environment: this parent starts one child per GPU BEFORE it makes any GPU call
-    (counting devices does not initialise one), relays rank 0's JSON line and fails if any rank fails."""
+    (counting devices does not initialise one), relays rank 0's JSON line and fails if any rank fails.  Every child is
+    polled: the first one to exit non-zero takes its siblings down with it (they would otherwise sit in the RCCL
+    rendezvous or a collective until its timeout)."""
     import torch
 
     have = torch.cuda.device_count()
     if have < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}")
     port = int(os.environ.get("MASTER_PORT", 29400 + os.getpid() % 2000))
-    procs = []
-    for rank in range(args.gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    procs, out0 = [], ROOT / "gpurun_out" / f".bench_rank0_{os.getpid()}.out"
+    out0.parent.mkdir(exist_ok=True)
+    with open(out0, "wb") as f0:
+        for rank in range(args.gpus):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                          stdout=f0 if rank == 0 else sys.stderr))
+        rcs = wait_all_or_kill(procs)
+    text = out0.read_text(errors="replace")
+    out0.unlink(missing_ok=True)
     if any(rcs):
         sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
         return 1
-    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     if not lines:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
         return 1
     print(lines[-1], flush=True)
     return 0
+
+
+def wait_all_or_kill(procs, poll_s: float = 0.2, grace_s: float = 5.0):
+    """Exit codes of `procs`; as soon as one exits non-zero the others are terminated (then killed after grace_s)."""
+    rcs = [None] * len(procs)
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0):
+                    failed = True
+        if failed:
+            deadline = time.time() + grace_s
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(poll_s)
+    return rcs
 
 
 def main() -> int:
@@ -339,9 +628,11 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    ap.add_argument("--nprobe", type=int, default=32, help="ivf1024 workload: lists probed per query")
+    ap.add_argument("--nprobe", type=int, default=0, help="IVF workloads: lists probed per query (0 = the config's set)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = every rank holds the workload's rows; strong = the rows are split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip plugin host-I/O timing and the gaussian1m leg")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only: no also.* legs")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
@@ -371,91 +662,190 @@ def main() -> int:
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    cpu_budget = 0.0 if args.no_cpu_baseline else 6.0
+
+    if world == 1 and os.environ.get("VDBHIP_BENCH_FORCE_SHARDED") != "1":
+        out = single_gpu_line(args, workload, vdbhip, torch, dev, local_rank, stream, cpu_budget)
+    else:
+        out = sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, stream)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def single_gpu_line(args, workload, vdbhip, torch, dev, local_rank, stream, cpu_budget):
+    n, d, nq, k, metric, gen = WORKLOADS[workload]
+    contract = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "rccl_ranks": 1}
+    if workload in ("ivf1024", "msmarco_ivf"):       # an IVF workload on its own (profiling runs): one point is the line
+        nlist = 1024 if workload == "ivf1024" else 100
+        probes = [args.nprobe] if args.nprobe > 0 else ([8, 32, 128] if workload == "ivf1024" else [32])
+        leg = ivf_leg(vdbhip, torch, dev, local_rank, stream, args.steps, args.warmup, probes, name=workload,
+                      nlist=nlist, cpu_budget_s=cpu_budget)
+        head = leg[f"nprobe{probes[-1]}"]
+        out = {"metric": f"QPS ({workload} IVF-Flat nlist={nlist} nprobe={probes[-1]}, k={k})", "value": head["value"],
+               "unit": "queries/s", **contract, "ms_per_step": head["ms_per_step"], "dtype": head["dtype"],
+               "data": "synthetic",
+               "config": {"workload": leg["config"] + "; inputs resident in HBM", "rows_per_gpu": n, "dim": d,
+                          "queries": nq, "k": k, "metric": metric, "nlist": nlist, "nprobe": probes[-1]},
+               "roofline": head["roofline"], "ivf": leg}
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        return out
+    if gen == "device_gaussian":
+        leg = device_corpus_line(args, workload, vdbhip, torch, dev, local_rank, stream)
+        leg.update(contract)
+        return leg
+
+    data_tag, GT, data = "synthetic", None, None
+    real = real_sift() if workload == "sift1m" else None
+    if real is not None:
+        Xr, Qr, GT, where = real
+        data = (Xr, Qr, 10, "l2")
+        data_tag = f"sift1m (real TEXMEX files from {where})"
+    head, kept = flat_leg(vdbhip, torch, workload, dev, local_rank, stream, args.steps, args.warmup,
+                          cpu_budget_s=cpu_budget * 1.6, data=data, keep_index=True, all_cpu_legs=(workload == "sift1m"))
+    algo, index, q_t, D_t, I_t, X, Q, ids = kept
+    n, d = X.shape
+    name = {"sift1m": "SIFT1M%s, 10k-query batch, k=10" % ("" if real else "-shaped")}.get(workload, f"{workload}, k={k}")
+    out = {"metric": f"QPS @ recall@10 ({name})", "value": head["value"], "unit": "queries/s", **contract,
+           "ms_per_step": head["ms_per_step"], "dtype": head["dtype"], "data": data_tag,
+           "config": {"workload": head["config"] + "; inputs resident in HBM", "rows_per_gpu": n, "dim": d, "queries": nq,
+                      "k": k, "metric": metric, "sharding": "none"},
+           "value_device_resident": head["value"]}
+    for key in ("value_host_io", "host_io_ms", "first_call_ms"):
+        if key in head:
+            out[key] = head[key]
+    out["value_note"] = HOST_IO_NOTE
+    for key in ("roofline", "pipeline", "cpu_baseline", "cpu_baselines", "recall@10_vs_cpu_blas_sample",
+                "ids_equal_cpu_oracle_first32"):
+        if key in head:
+            out[key] = head[key]
+    if int(head["roofline"]["peak"]) == int(PEAK_I8_TOPS):
+        out["dtype_note"] = ("the int8 scan serves byte-valued corpora with integer queries only (SIFT descriptors are uint8); "
+                             "one non-integer query value puts the batch on the fp16 scan of the same index: "
+                             "also.gaussian1m is that case")
+    if GT is not None:
+        out["recall@10_vs_sift_groundtruth"] = round(recall_vs(GT[:, :k], ids, k), 6)
+    if args.no_extras or workload != "sift1m":
+        index.close()
+        return out
+
+    also = {}
+    also["serving"] = {"sift1m": serving_leg(vdbhip, torch, dev, local_rank, stream, index, q_t, k, n, d, "sift1m")}
+    index.close()
+    del X, Q, kept, algo
+    also["gaussian1m"] = flat_leg(vdbhip, torch, "gaussian1m", dev, local_rank, stream, args.steps, args.warmup,
+                                  cpu_budget_s=cpu_budget * 0.7)
+    also["glove1.2m"] = flat_leg(vdbhip, torch, "glove1.2m", dev, local_rank, stream, args.steps, args.warmup,
+                                 cpu_budget_s=cpu_budget)
+    also["ivf1024"] = ivf_leg(vdbhip, torch, dev, local_rank, stream, args.steps, args.warmup, [8, 32, 128],
+                              cpu_budget_s=cpu_budget * 0.8)
+    also["msmarco_ivf"] = ivf_leg(vdbhip, torch, dev, local_rank, stream, args.steps, args.warmup, [32],
+                                  name="msmarco_ivf", nlist=100, cpu_budget_s=cpu_budget * 0.8)
+    # serving on a scan copy larger than the Infinity Cache: 4M x 128 byte-valued rows = 512 MB of int8 panels
+    n4, d4, _, k4, m4, _ = WORKLOADS["bytes4m"]
+    X4 = device_byte_rows(n4, d4, dev, 77)
+    i4 = vdbhip.FlatIndex(d4, m4, local_rank)
+    i4.add_device(X4.data_ptr(), n4, id_base=0)
+    del X4
+    torch.cuda.empty_cache()
+    q4_t = device_byte_rows(64, d4, dev, 78)
+    also["serving"]["bytes4m"] = serving_leg(vdbhip, torch, dev, local_rank, stream, i4, q4_t, k4, n4, d4, "bytes4m")
+    i4.close()
+    torch.cuda.empty_cache()
+    also["marco12.5m"] = scaling_reference_leg(vdbhip, torch, dev, local_rank, stream, min(args.steps, 10),
+                                               min(args.warmup, 2))
+    out["also"] = also
+    return out
+
+
+def device_corpus_line(args, workload, vdbhip, torch, dev, local_rank, stream):
+    """A device-generated workload (marco12.5m, gauss50m) on one GPU, plain (non-sharded) search path."""
+    n, d, nq, k, metric, _ = WORKLOADS[workload]
+    _, Q, _, _ = make_data(workload, 0)
+    X_t = device_rows(n, d, 0, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = vdbhip.FlatIndex(d, metric, local_rank)
+    index.add_device(X_t.data_ptr(), n, id_base=0)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    q_t = torch.from_numpy(Q).to(dev)
+    D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    el, st = timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, args.steps, args.warmup, torch)
+    out = {"metric": f"QPS ({workload}, k={k})", "value": round(nq * args.steps / el, 1), "unit": "queries/s",
+           "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": scan_dtype_name(st), "data": "synthetic",
+           "config": {"workload": f"{workload}: {n} rows x {d} dims per GPU, {nq} queries, k={k}, {metric}; brute-force "
+                                  f"exact k-NN; rows generated on device; inputs resident in HBM",
+                      "rows_per_gpu": n, "dim": d, "queries": nq, "k": k, "metric": metric, "sharding": "none"},
+           "roofline": roofline_of(st, nq, n, d, workload),
+           "pipeline": pipeline_of(st, nq, build_s, float(n) * d * 4),
+           "recall@10_vs_float64_torch_sample": round(device_check(X_t, q_t, I_t, k, metric, 0), 6),
+           "result_checksum": result_checksum(I_t)}
+    index.close()
+    return out
+
+
+def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, stream):
+    """N > 1 (or the one-rank rehearsal VDBHIP_BENCH_FORCE_SHARDED=1): row shards, ONE all-gather of packed partials, merge."""
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
-
-    n, d = WORKLOADS[workload][:2]
-    data_tag, GT = "synthetic", None
-    real = real_sift() if workload in ("sift1m", "ivf1024") and world == 1 else None
-    if real is not None:
-        X, Q, GT, where = real
-        k, metric = 10, "l2"
-        n, d = X.shape
-        data_tag = f"sift1m (real TEXMEX files from {where})"
+    n_total, d, nq, k, metric, gen = WORKLOADS[workload]
+    strong = args.scaling == "strong"
+    if strong:
+        if gen != "device_gaussian":
+            raise SystemExit("--scaling strong needs a device-generated workload (marco12.5m)")
+        lo, hi = n_total * rank // world, n_total * (rank + 1) // world
+    else:
+        lo, hi = rank * n_total, (rank + 1) * n_total      # (global row ids; host-generated shards are seeded by rank)
+    n = hi - lo
+    if gen == "device_gaussian":
+        _, Q, _, _ = make_data(workload, 0)
+        X_t = device_rows_range(lo, hi, d, dev) if strong else device_rows(n, d, rank, dev)
+        X = None
     else:
         X, Q, k, metric = make_data(workload, rank)
-    nq = Q.shape[0]
-    X_t = device_rows(n, d, rank, dev) if X is None else None
+        X_t = None
     torch.cuda.synchronize()
-    ivf = workload == "ivf1024"
-    extras = {}
     t0 = time.perf_counter()
-    if ivf:
-        index = vdbhip.IVFFlatIndex(d, 1024, metric, local_rank)
-        index.train(X, niter=25, seed=1234, max_points_per_centroid=256)
-        extras["train_s"] = round(time.perf_counter() - t0, 3)
-        index.add(X)
-        index.set_nprobe(args.nprobe)
-    elif X is None:
-        index = vdbhip.FlatIndex(d, metric, local_rank)
-        index.add_device(X_t.data_ptr(), n, id_base=rank * n)
-        torch.cuda.synchronize()
-    elif world == 1 and not args.no_extras:
-        # the reference harness's view first, in a fresh process state (experiment_runner.py:330, 431-437: build_index,
-        # then batch_search timed with time.time(), NO warm-up): pageable NumPy queries in, NumPy (D, I) out
-        algo = vdbhip.get_algorithm_instance("HipExactSearch", d, name="bench", metric=metric, device=local_rank)
-        algo.build_index(X)
-        extras["build_s_plugin"] = round(time.perf_counter() - t0, 3)
-        t1 = time.time()
-        algo.batch_search(Q, k=k)
-        extras["first_call_ms"] = round((time.time() - t1) * 1e3, 3)
-        for _ in range(3):
-            algo.batch_search(Q, k=k)
-        times = []
-        for _ in range(11):
-            t1 = time.time()
-            algo.batch_search(Q, k=k)
-            times.append(time.time() - t1)
-        med = float(np.median(times))
-        extras["qps_plugin_host_io"] = round(nq / med, 1)
-        extras["plugin_host_io_ms"] = round(med * 1e3, 4)
-        extras["plugin_host_io_note"] = ("HipExactSearch.batch_search(Q (10000,128) pageable numpy) -> numpy (D, I): H2D of Q "
-                                         "and D2H of the result inside the timed call; median of 11 after 3 warm-ups; "
-                                         "first_call_ms = the very first call after build_index, no warm-up search "
-                                         "(build_index sizes the workspace for 10 000 queries: vdb_reserve)")
-        index = algo.index
+    index = vdbhip.FlatIndex(d, metric, local_rank)
+    if X is None:
+        index.add_device(X_t.data_ptr(), n, id_base=lo)
     else:
-        index = vdbhip.FlatIndex(d, metric, local_rank)
-        index.add(X, id_base=rank * n)
+        index.add(X, id_base=lo)
+    torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
 
-    stream = torch.cuda.current_stream().cuda_stream
     q_t = torch.from_numpy(Q).to(dev)
     D_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I_t = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    sharded = world > 1 or os.environ.get("VDBHIP_BENCH_FORCE_SHARDED") == "1"   # (rehearsal of the N>1 code path)
-    if sharded:
-        # one packed buffer per rank: keys (nq*k float64) immediately followed by ids (nq*k int64) -> ONE all-gather
-        my_pack = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
-        all_pack = torch.empty((world, 2, nq, k), dtype=torch.int64, device=dev)
+    # one packed buffer per rank: keys (nq*k float64) immediately followed by ids (nq*k int64) -> ONE all-gather
+    my_pack = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
+    all_pack = torch.empty((world, 2, nq, k), dtype=torch.int64, device=dev)
 
     def local_step():
         index.search_partial_device(q_t.data_ptr(), nq, k, my_pack[0].data_ptr(), my_pack[1].data_ptr(), stream)
 
-    def step():
-        if not sharded:
-            index.search_device(q_t.data_ptr(), nq, k, D_t.data_ptr(), I_t.data_ptr(), stream)
+    def exchange_step():
+        if world > 1:
+            dist.all_gather_into_tensor(all_pack, my_pack)
         else:
-            local_step()
-            if world > 1:
-                dist.all_gather_into_tensor(all_pack, my_pack)
-            else:
-                all_pack.copy_(my_pack.unsqueeze(0))
-            vdbhip.merge_packed_partials_device(metric, local_rank, all_pack.data_ptr(), world, nq, k,
-                                                D_t.data_ptr(), I_t.data_ptr(), stream)
+            all_pack.copy_(my_pack.unsqueeze(0))
+        vdbhip.merge_packed_partials_device(metric, local_rank, all_pack.data_ptr(), world, nq, k,
+                                            D_t.data_ptr(), I_t.data_ptr(), stream)
+
+    def step():
+        local_step()
+        exchange_step()
 
     def fence():
         torch.cuda.synchronize()
@@ -463,148 +853,65 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, reps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         step()
-    fence()
-    shard_alone_ms = None
-    if sharded:      # this rank's shard scan without the exchange (untimed region): what the collective + merge add
-        t0 = time.perf_counter()
-        for _ in range(3):
-            local_step()
-        torch.cuda.synchronize()
-        shard_alone_ms = (time.perf_counter() - t0) / 3 * 1e3
-        fence()
+    # untimed side measurements: this rank's shard scan without the exchange, and the exchange (all-gather + merge) alone
+    shard_alone_ms = timed(local_step, 3) / 3 * 1e3
+    exchange_ms = timed(exchange_step, 10) / 10 * 1e3
     index.set_option("timing", 1)      # HIP events around the scan kernel, on the search stream, per step
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step, args.steps)
     st = index.stats()
     index.set_option("timing", 0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * nq * args.steps / elapsed
-    rows_probed = None
-    if ivf:
-        rows_probed = float(st.get("last_rows_scanned", 0)) or nq * args.nprobe / 1024.0 * n
-    roof = roofline_of(st, nq, n, d, workload, ivf_rows_probed=rows_probed)
-    if ivf:      # the list scan is HBM-bound per query unless queries are grouped per list -- report both
-        bytes_q = 4.0 * d * rows_probed            # float32 rows each (query, probe) pair would read un-grouped
-        roof["hbm_equiv"] = {"bound": "hbm", "achieved": round(bytes_q / (roof["kernel_ms"] * 1e-3) / 1e9, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "note": "4*D bytes x (query, row) pairs scanned / scan time: what a per-query list scan "
-                                     "would have to stream; the list-major scan reads each list once per query group"}
-    i8 = int(st.get("scan_dtype", 0)) == 1
-    dtype = ("i8 MFMA scan (i32 accumulate) + f64 exact refine" if i8
-             else "f16 MFMA scan (f32 accumulate) + f64 exact refine")
-
-    if workload == "sift1m":
-        metric_name = "QPS @ recall@10 (SIFT1M%s, 10k-query batch, k=10)" % ("" if real else "-shaped")
-    elif ivf:
-        metric_name = f"QPS (SIFT1M-shaped IVF-Flat nlist=1024 nprobe={args.nprobe}, k={k})"
-    else:
-        metric_name = f"QPS ({workload}, k={k})"
+    qps_corpus = nq * args.steps / elapsed
+    value = qps_corpus if strong else world * qps_corpus
+    corpus_rows = n_total if strong else world * n_total
     out = {
-        "metric": metric_name,
+        "metric": f"QPS ({workload}, k={k}" + (", strong scaling: whole-corpus queries/s)" if strong
+                                              else ", weak scaling: query x shard scans/s)"),
         "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": data_tag,
-        "config": {"workload": f"{workload}: {n} rows x {d} dims per GPU, {nq} queries, k={k}, {metric}; "
-                               + ("IVF-Flat nlist=1024 nprobe=%d, own k-means; " % args.nprobe if ivf
-                                  else "brute-force exact k-NN; ") + "inputs resident in HBM",
-                   "rows_per_gpu": n, "dim": d, "queries": nq, "k": k, "metric": metric,
-                   "sharding": "none" if world == 1 else
-                   f"row-sharded x{world} (weak scaling: corpus = {world} x {n} rows), RCCL all-gather of partial top-k"},
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": scan_dtype_name(st), "data": "synthetic",
+        "config": {"workload": f"{workload}: {n} rows x {d} dims on this GPU, {nq} queries, k={k}, {metric}; brute-force "
+                               f"exact k-NN; inputs resident in HBM",
+                   "rows_per_gpu": n, "corpus_rows": corpus_rows, "dim": d, "queries": nq, "k": k, "metric": metric,
+                   "sharding": (f"row-sharded x{world} (strong scaling: the {n_total}-row corpus split over the ranks)"
+                                if strong else
+                                f"row-sharded x{world} (weak scaling: corpus = {world} x {n_total} rows)")
+                               + ", RCCL all-gather of packed partial top-k + merge on every rank"},
         "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
-        "roofline": roof,
-        "pipeline": {"path": st["last_path_name"], "candidates_per_query": round(st["last_candidates"] / nq, 2),
-                     "rescan_bins": int(st["last_rescan_bins"]), "fallback_queries": int(st["last_fallback_queries"]),
-                     "corpus_fp16_exact": int(st["corpus_fp16_exact"]), "build_s": round(build_s, 3),
-                     "hbm_resident_mb": round(st["bytes_resident"] / 2 ** 20, 1)},
+        "roofline": roofline_of(st, nq, n, d, workload),
+        "pipeline": pipeline_of(st, nq, build_s, float(n) * d * 4),
+        "qps_whole_corpus": round(qps_corpus, 1),
+        "shard_scan_alone_ms": round(shard_alone_ms, 4),
+        "exchange_ms": round(exchange_ms, 4),
+        "exchange_note": f"all_gather_into_tensor of {my_pack.numel() * 8} bytes per rank + merge of {world} partial lists "
+                         f"per query, timed alone (10 repetitions, max over ranks)",
+        "result_checksum": result_checksum(I_t),
+        "scaling_reference": ("the N = 1 point of this workload is `also[\"%s\"]` of the `--gpus 1` line (value, "
+                              "result_checksum), or `--gpus 1 --workload %s`: the default N = 1 workload is sift1m, a "
+                              "different problem" % (workload, workload)),
     }
-    out.update(extras)
-    if world > 1 or sharded:
-        out["qps_whole_corpus"] = round(nq * args.steps / elapsed, 1)
-        out["shard_scan_alone_ms"] = round(shard_alone_ms, 4) if shard_alone_ms else None
-        out["scaling_reference"] = ("the N = 1 point of this workload is `also[\"%s\"].value` of the `--gpus 1` line (or "
-                                    "`--gpus 1 --workload %s`): the default N = 1 workload is sift1m, a different "
-                                    "problem" % (workload, workload))
-
-    gpu_ids = I_t.cpu().numpy()
-    if GT is not None:
-        out["recall@10_vs_sift_groundtruth"] = round(recall_vs(GT[:, :k], gpu_ids, k), 6)
-    if ivf:
-        flat = vdbhip.FlatIndex(d, metric, local_rank)
-        flat.add(X)
-        _, ie = flat.search(Q, k)
-        flat.close()
-        out["recall@10_vs_exact"] = round(recall_vs(ie, gpu_ids, k), 6)
-        if not args.no_cpu_baseline:
-            # CPU leg of config 4 ("vs FAISS-CPU": faiss is not installed, so the C restatement of the same IVF-Flat
-            # search -- same centroids, same lists, OpenMP over queries -- on a bounded query sample; its ids double as
-            # a bit-level check of the GPU result)
-            from oracle import c_oracle
-
-            c_oracle.build()
-            C, lor = index.centroids(), index.assignment()
-            probe = 256
-            t1 = time.perf_counter()
-            c_oracle.ivf_search(X, C, lor, Q[:probe], k, args.nprobe, metric)
-            dt = time.perf_counter() - t1
-            sample = int(min(nq, max(probe, probe * 8.0 / max(dt, 1e-6))))
-            t1 = time.perf_counter()
-            _, io_ = c_oracle.ivf_search(X, C, lor, Q[:sample], k, args.nprobe, metric)
-            dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "queries/s", "cores": c_oracle.num_threads(),
-                                   "kind": "port", "impl": "oracle/ivf_oracle.c (canonical float64 list scan, OpenMP)",
-                                   "sample": f"first {sample} of {nq} queries, nprobe {args.nprobe}, {dt:.1f} s"}
-            out["ids_equal_cpu_oracle_sample"] = bool(np.array_equal(io_, gpu_ids[:sample]))
     if X is None:
-        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, rank * n, dist=dist,
+        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, lo, dist=dist,
                                                                        world=world), 6)
-    elif rank == 0 and world == 1 and not ivf:
-        if workload == "sift1m" and not args.no_extras:
-            # second timed workload of the same run: Gaussian 1M (corpus NOT exact in fp16 -> non-trivial guard)
-            Xg, Qg, kg, mg = make_data("gaussian1m", 0)
-            gi = vdbhip.FlatIndex(Xg.shape[1], mg, local_rank)
-            gi.add(Xg)
-            qg_t = torch.from_numpy(Qg).to(dev)
-            el, sg = timed_device_loop(gi, qg_t, len(Qg), kg, D_t, I_t, stream, args.steps, args.warmup, torch)
-            from oracle import c_oracle
-
-            _, io_ = c_oracle.knn(Xg, Qg[:32], kg, mg)
-            out["also"] = {"gaussian1m": {
-                "value": round(len(Qg) * args.steps / el, 1), "unit": "queries/s",
-                "ms_per_step": round(el / args.steps * 1e3, 4),
-                "roofline": roofline_of(sg, len(Qg), Xg.shape[0], Xg.shape[1], "gaussian1m"),
-                "candidates_per_query": round(sg["last_candidates"] / len(Qg), 2),
-                "rescan_bins": int(sg["last_rescan_bins"]), "fallback_queries": int(sg["last_fallback_queries"]),
-                "corpus_fp16_exact": int(sg["corpus_fp16_exact"]),
-                "ids_equal_cpu_oracle_first32": bool(np.array_equal(I_t[:32].cpu().numpy(), io_))}}
-            gi.close()
-            del Xg, Qg
-            out["also"]["serving"] = serving_leg(index, q_t, k, D_t, I_t, stream, torch, n, d)
-            index.close()
-            out["also"]["marco12.5m"] = scaling_reference_leg(vdbhip, torch, dev, local_rank, stream,
-                                                              min(args.steps, 10), min(args.warmup, 2))
-        if not args.no_cpu_baseline:
-            legs, recall = cpu_baselines(X, Q, k, metric, gpu_ids)
-            out["cpu_baseline"] = legs["blas_gemm_expansion"]
-            out["cpu_baselines"] = legs
-            out["recall@10_vs_cpu_blas_sample"] = round(recall, 6)
     if world > 1:
         dist.destroy_process_group()
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    return 0
+    return out
 
 
 if __name__ == "__main__":

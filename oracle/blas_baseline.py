@@ -154,23 +154,25 @@ def gemm_expansion_knn(X: np.ndarray, Q: np.ndarray, k: int, metric: str, qblock
     return D, I
 
 
-def time_gemm_expansion(X, Q, k, metric, budget_s: float = 12.0):
-    """(result dict, ids of the timed sample): warm the BLAS threads on one block, then time a bounded sample."""
+def time_gemm_expansion(X, Q, k, metric, budget_s: float = 12.0, threads: int = 0):
+    """(result dict, ids of the timed sample): warm the BLAS threads on one block, then time a bounded sample.
+    `threads` = select threads AND the number the caller has limited the BLAS to (bench.py: threadpool_limits) -- one
+    figure, reported as `cores`; 0 = usable_cpus()."""
     info = blas_info()
+    cpus = threads or usable_cpus()
     probe = min(len(Q), 1024)
     t0 = time.perf_counter()
-    gemm_expansion_knn(X, Q[:probe], k, metric)
+    gemm_expansion_knn(X, Q[:probe], k, metric, select_threads=cpus)
     dt = time.perf_counter() - t0
     sample = int(min(len(Q), max(probe, (budget_s / max(dt, 1e-6)) * probe)))
     sample = max(1024, sample // 1024 * 1024) if len(Q) >= 1024 else len(Q)
     sample = min(sample, len(Q))
     t0 = time.perf_counter()
-    _, ids = gemm_expansion_knn(X, Q[:sample], k, metric)
+    _, ids = gemm_expansion_knn(X, Q[:sample], k, metric, select_threads=cpus)
     dt = time.perf_counter() - t0
-    cpus = usable_cpus()
     return {"value": round(sample / dt, 2), "unit": "queries/s", "cores": cpus, "kind": "port",
             "impl": "oracle/blas_baseline.py gemm_expansion_knn: float32 GEMM expansion via NumPy's threaded "
-                    f"{info.get('blas')} ({info.get('blas_threads')} BLAS threads configured, {cpus} CPUs usable of "
+                    f"{info.get('blas')} ({info.get('blas_threads')} BLAS threads, {cpus} CPUs usable of "
                     f"{os.cpu_count()}), 1024 x 32768 blocks, heap-top filter + per-block merge on {cpus} threads",
             "sample": f"first {sample} of {len(Q)} queries against all {len(X)} rows, {dt:.1f} s", **info}, ids
 

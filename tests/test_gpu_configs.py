@@ -82,6 +82,79 @@ def test_config4_ivf1024_sift1m_nprobe_8_32_128(vdb, oracle):
     idx.close()
 
 
+def _plain_lloyd(X, nlist, niter, seed):
+    """A plain Lloyd run (float32 BLAS assignment, float64 means, empty cells keep their centre), first-nlist-draws
+    initialisation from a seeded permutation: the yardstick for the library's k-means objective."""
+    rng = np.random.default_rng(seed)
+    S = X[rng.permutation(len(X))[:min(len(X), 256 * nlist)]]
+    C = S[:nlist].astype(np.float64)
+    for _ in range(niter):
+        Cf = C.astype(np.float32)
+        a = np.empty(len(S), np.int64)
+        for lo in range(0, len(S), 65536):
+            blk = S[lo:lo + 65536]
+            a[lo:lo + 65536] = np.argmin((Cf * Cf).sum(1)[None, :] - 2.0 * (blk @ Cf.T), axis=1)
+        order = np.argsort(a, kind="stable")
+        counts = np.bincount(a, minlength=nlist)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        sums = np.add.reduceat(S[order].astype(np.float64), np.minimum(starts, len(S) - 1), axis=0)
+        live = counts > 0
+        C[live] = sums[live] / counts[live, None]
+    return C.astype(np.float32)
+
+
+def test_config4_with_the_librarys_own_quantizer(vdb, oracle):
+    """BASELINE config 4 as the reference runs it (modular.py:277-286: index.train then index.add), at its stated size:
+    vdb_ivf_train on 1M x 128, nlist 1024, 25 iterations, seed 1234.  The quantizer is deterministic, leaves no list
+    empty, reaches the objective of a plain Lloyd run, and the search on ITS centroids equals the CPU restatement of
+    IVF-Flat on those centroids bit for bit at nprobe 8 / 32 / 128."""
+    from vdbhip import datasets
+    from vdbhip.metrics import recall_at_k
+
+    X, Q = datasets.sift_like(1_000_000, 10_000, 128, 1234)
+    nlist, k = 1024, 10
+    idx = vdb.IVFFlatIndex(128, nlist, "l2", 0)
+    idx.train(X, niter=25, seed=1234, max_points_per_centroid=256)
+    C = idx.centroids()
+    assert np.isfinite(C).all() and len(np.unique(C, axis=0)) == nlist
+    again = vdb.IVFFlatIndex(128, nlist, "l2", 0)
+    again.train(X, niter=25, seed=1234, max_points_per_centroid=256)
+    np.testing.assert_array_equal(again.centroids(), C)              # same seed, same centroids, bit for bit
+    again.train(X, niter=25, seed=99, max_points_per_centroid=256)
+    assert not np.array_equal(again.centroids(), C)
+    again.close()
+    held_out = X[np.random.default_rng(11).choice(len(X), 100_000, replace=False)]
+    obj = oracle.kmeans_objective(C, held_out)
+    obj_ref = oracle.kmeans_objective(_plain_lloyd(X, nlist, 25, 1234), held_out)
+    print(f"k-means objective on 100k held-out rows: library {obj:.1f}, plain Lloyd {obj_ref:.1f} ({obj / obj_ref - 1:+.2%})")
+    assert obj <= obj_ref * 1.05, (obj, obj_ref)
+    idx.add(X)
+    lor = idx.assignment()
+    sizes = np.bincount(lor, minlength=nlist)
+    assert sizes.min() > 0 and sizes.sum() == len(X), (sizes.min(), sizes.max())
+    rows = np.random.default_rng(6).choice(len(X), 50_000, replace=False)
+    np.testing.assert_array_equal(lor[rows], oracle.ivf_assign(C, X[rows], "l2"))
+    exact = vdb.FlatIndex(128, "l2", 0)
+    exact.add(X)
+    _, Ie = exact.search(Q, k)
+    exact.close()
+    sample = np.random.default_rng(7).choice(len(Q), 64, replace=False)
+    recalls = []
+    for nprobe in (8, 32, 128):
+        idx.set_nprobe(nprobe)
+        D, I = idx.search(Q, k)
+        st = idx.stats()
+        assert st["last_path_name"] == "ivf" and st["last_candidates"] > 0 and st["last_fallback_queries"] == 0, st
+        _properties(D, I, 0, len(X), "l2")
+        Do, Io = oracle.ivf_search(X, C, lor, Q[sample], k, nprobe, "l2")
+        np.testing.assert_array_equal(I[sample], Io)
+        np.testing.assert_array_equal(D[sample], Do)
+        recalls.append(recall_at_k(Ie, I, 10))
+    print("recall@10 vs exact at nprobe 8 / 32 / 128:", [round(r, 4) for r in recalls])
+    assert recalls[0] < recalls[1] < recalls[2] and recalls[2] > 0.9, recalls
+    idx.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # config 5 (per-GPU shard)
 # ---------------------------------------------------------------------------------------------------------
@@ -184,6 +257,26 @@ def test_published_random_ivf100_recall_point(vdb, golden_dir):
     _, ii = ivf.batch_search(q, k=topk)
     r10, r1 = recall_at_k(g, ii, 10), recall_at_k(g, ii, 1)
     # FAISS's k-means is not reproducible without FAISS; on i.i.d. Gaussian data any Lloyd clustering into 100 cells
-    # probed 10 deep lands in the same neighbourhood
-    assert abs(r10 - pub["ivf_flat"]["recall@10"]) <= 0.05, (r10, pub["ivf_flat"]["recall@10"])
-    assert abs(r1 - pub["ivf_flat"]["recall@1"]) <= 0.08, (r1, pub["ivf_flat"]["recall@1"])
+    # probed 10 deep lands in the same neighbourhood.  How wide that neighbourhood is, is measured: ten seeds of the
+    # library's own k-means (tests/golden/own_measurements.json holds the span recorded on an MI355X and the band).
+    span10, span1 = [r10], [r1]
+    for seed in range(1, 10):
+        alt = vdb.CompositeAlgorithm("ivf_flat", opt["dimensions"],
+                                     indexer={"type": "HipIVFIndexer", "metric": "l2", "index_type": pub["index_type"],
+                                              "nprobe": pub["nprobe"], "seed": seed},
+                                     searcher={"type": "HipIVFSearcher", "metric": "l2", "nprobe": pub["nprobe"]},
+                                     metric="l2")
+        alt.build_index(train)
+        _, ia = alt.batch_search(q, k=topk)
+        span10.append(recall_at_k(g, ia, 10))
+        span1.append(recall_at_k(g, ia, 1))
+    print(f"published recall@10 {pub['ivf_flat']['recall@10']:.4f} / recall@1 {pub['ivf_flat']['recall@1']:.4f}; "
+          f"own k-means seed 1234: {r10:.4f} / {r1:.4f}; ten seeds: recall@10 {min(span10):.4f}..{max(span10):.4f}, "
+          f"recall@1 {min(span1):.4f}..{max(span1):.4f}")
+    rec = json.loads((golden_dir / "own_measurements.json").read_text())["random_ivf_flat_own_kmeans_ten_seeds"]
+    tol10, tol1 = rec["tolerance_recall@10"], rec["tolerance_recall@1"]
+    assert abs(r10 - pub["ivf_flat"]["recall@10"]) <= tol10, (r10, pub["ivf_flat"]["recall@10"])
+    assert abs(r1 - pub["ivf_flat"]["recall@1"]) <= tol1, (r1, pub["ivf_flat"]["recall@1"])
+    # a regression of vdb_ivf_train shows as ALL seeds drifting: the seed mean must sit on the published point
+    assert abs(float(np.mean(span10)) - pub["ivf_flat"]["recall@10"]) <= rec["tolerance_mean_recall@10"], span10
+    assert max(span10) - min(span10) <= 2 * tol10 and max(span1) - min(span1) <= 2 * tol1

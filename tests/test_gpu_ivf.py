@@ -214,6 +214,30 @@ def test_ivf_persistence_round_trip(vdb, tmp_path):
     c = vdb.get_algorithm_instance("HipApproximateSearch", 16, name="ivf3", index_type="IVF32,Flat", metric="l2")
     with pytest.raises(ValueError):
         c.load_index(str(tmp_path / "art"))
+    # files that do not belong together are refused: a regenerated corpus, a quantizer from another run --
+    # through the stored fingerprint, and for artifacts written before it existed through a sampled re-assignment
+    import json
+    import shutil
+
+    for victim, make in (("vectors.npy", lambda: _data(6000, 16, 1, 9)[0]),
+                         ("centroids.npy", lambda: np.load(tmp_path / "art" / "centroids.npy")[::-1].copy())):
+        for drop_fingerprint in (False, True):
+            bad = tmp_path / f"bad_{victim}_{int(drop_fingerprint)}"
+            shutil.copytree(tmp_path / "art", bad)
+            np.save(bad / victim, make(), allow_pickle=False)
+            if drop_fingerprint:
+                m = json.loads((bad / "manifest.json").read_text())
+                m.pop("sha256")
+                (bad / "manifest.json").write_text(json.dumps(m))
+            with pytest.raises(ValueError, match="do not belong together|do not match"):
+                b.load_index(str(bad))
+    old = tmp_path / "old_format"           # an intact artifact without the fingerprint still loads
+    shutil.copytree(tmp_path / "art", old)
+    m = json.loads((old / "manifest.json").read_text())
+    m.pop("sha256")
+    (old / "manifest.json").write_text(json.dumps(m))
+    b.load_index(str(old), context={"config_hash": "abc"})
+    np.testing.assert_array_equal(b.batch_search(Q, k=5)[1], i0)
     (tmp_path / "art" / "WRITE_COMPLETE").unlink()
     with pytest.raises(FileNotFoundError):
         b.load_index(str(tmp_path / "art"))

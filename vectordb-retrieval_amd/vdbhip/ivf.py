@@ -137,6 +137,36 @@ class IVFFlatIndex:
         _ffi.check(self._lib.vdb_set_option(self._h, key.encode(), float(value)), build_time=True)
 
 
+def _fingerprint(vectors: np.ndarray, centroids: np.ndarray, list_of_row: np.ndarray) -> dict:
+    """What a persisted index records about its three files so that load_index can tell a vectors / centroids file that
+    does not belong to list_of_row.npy (regenerated corpus, partial overwrite): SHA-256 of the centroids and of the lists
+    in full, and of up to 4096 evenly spaced corpus rows (hashing a memory-mapped 38 GB shard in full is not cheap)."""
+    import hashlib
+
+    n = int(vectors.shape[0])
+    pick = np.unique(np.linspace(0, max(n - 1, 0), num=min(n, 4096)).astype(np.int64)) if n else np.zeros(0, np.int64)
+    rows = np.ascontiguousarray(np.asarray(vectors[pick], dtype=np.float32))
+    return {"centroids": hashlib.sha256(np.ascontiguousarray(centroids, np.float32).tobytes()).hexdigest(),
+            "list_of_row": hashlib.sha256(np.ascontiguousarray(list_of_row, np.int32).tobytes()).hexdigest(),
+            "vectors_sample": hashlib.sha256(rows.tobytes()).hexdigest(), "vectors_sample_rows": int(len(pick)),
+            "vectors_shape": [n, int(vectors.shape[1]) if vectors.ndim == 2 else 0]}
+
+
+def _lists_match_sample(vectors, centroids, list_of_row, metric: str, rows: int = 512) -> bool:
+    """Artifacts written before the fingerprint existed: re-assign a few hundred rows against the stored centroids
+    (float64; a row within 1e-9 relative of a tie may sit in either list) and compare with the stored lists."""
+    n = int(vectors.shape[0])
+    if n == 0:
+        return True
+    pick = np.unique(np.linspace(0, n - 1, num=min(n, rows)).astype(np.int64))
+    x = np.asarray(vectors[pick], dtype=np.float64)
+    c = np.asarray(centroids, dtype=np.float64)
+    score = -(x @ c.T) if metric == "ip" else (c * c).sum(1)[None, :] - 2.0 * (x @ c.T)
+    best = score.min(axis=1)
+    stored = score[np.arange(len(pick)), np.asarray(list_of_row)[pick]]
+    return bool(np.all(stored - best <= 1e-9 * np.maximum(1.0, np.abs(best))))
+
+
 def _build_ivf(vectors: np.ndarray, dim: int, key: str, metric: str, device: int, params: dict) -> IVFFlatIndex:
     index = IVFFlatIndex(dim, parse_ivf_key(key), metric, device)
     index.train(vectors, niter=int(params.get("niter", 25)), seed=int(params.get("seed", 1234)),
@@ -204,14 +234,16 @@ class HipApproximateSearch(BaseAlgorithm):
             shutil.rmtree(target)
         tmp = Path(tempfile.mkdtemp(prefix=f".{target.name}.tmp.", dir=str(target.parent)))
         try:
+            centroids, lists = self.index.centroids(), self.index.assignment()
             np.save(tmp / "vectors.npy", self.vectors, allow_pickle=False)
-            np.save(tmp / "centroids.npy", self.index.centroids(), allow_pickle=False)
-            np.save(tmp / "list_of_row.npy", self.index.assignment(), allow_pickle=False)
+            np.save(tmp / "centroids.npy", centroids, allow_pickle=False)
+            np.save(tmp / "list_of_row.npy", lists, allow_pickle=False)
             build_metrics = dict(context.get("build_metrics", {}))
             manifest = {"format": self._FORMAT, "algorithm": type(self).__name__, "dimension": self.dimension,
                         "index_type": self.index_type, "metric": self.metric, "nlist": self.index.nlist,
                         "nprobe": self.index.nprobe, "n_vectors": int(self.index.ntotal),
                         "config_hash": context.get("config_hash"),
+                        "sha256": _fingerprint(self.vectors, centroids, lists),
                         "files": {"vectors": "vectors.npy", "centroids": "centroids.npy",
                                   "list_of_row": "list_of_row.npy"}}
             (tmp / "manifest.json").write_text(json.dumps(manifest, indent=2), encoding="utf-8")
@@ -250,6 +282,16 @@ class HipApproximateSearch(BaseAlgorithm):
         stored = np.load(path / manifest["files"]["list_of_row"])
         if stored.shape != (vectors.shape[0],) or (len(stored) and (stored.min() < 0 or stored.max() >= int(manifest["nlist"]))):
             raise ValueError("Persisted inverted lists do not match the persisted corpus")
+        # the three files must be the ones that were written together: a corpus or quantizer that does not belong to the
+        # stored lists would load silently and answer with degraded recall
+        want = manifest.get("sha256")
+        if want:
+            have = _fingerprint(vectors, centroids, stored)
+            bad = [key for key in ("vectors_shape", "vectors_sample", "centroids", "list_of_row") if have[key] != want.get(key)]
+            if bad:
+                raise ValueError("Persisted index files do not belong together (fingerprint mismatch: " + ", ".join(bad) + ")")
+        elif not _lists_match_sample(vectors, centroids, stored, self.metric):
+            raise ValueError("Persisted inverted lists do not match the persisted corpus and centroids")
         self.index.add(vectors, list_of_row=stored)   # ... and so are the stored lists: no assignment pass either
         self.index.set_nprobe(int(self.config.get("nprobe", manifest.get("nprobe", 1))))
         self.index_built = True
