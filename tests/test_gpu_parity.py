@@ -669,6 +669,35 @@ def test_graph_replay_of_a_serving_loop_is_exact(vdb, oracle):
         side.synchronize()
         np.testing.assert_array_equal(I_t.cpu().numpy(), Io[24 * call:24 * call + 24], err_msg=f"after growth, call {call}")
     assert idx.stats()["graph_replays"] == 7                # eager, captured + launched, replayed
+    # a buffer of this process moves BETWEEN two replays of the same key (another index is built and closed): the
+    # allocation-epoch check must drop the captured graph -- it holds raw addresses -- and capture again
+    other = vdb.FlatIndex(96, "l2", 0)
+    other.add(X[:5000])
+    other.search(Q[:8], 10)
+    other.close()
+    for call in range(3, 6):
+        with torch.cuda.stream(side):
+            q_t.copy_(torch.from_numpy(Q[24 * call:24 * call + 24]))
+        idx.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        np.testing.assert_array_equal(I_t.cpu().numpy(), Io[24 * call:24 * call + 24], err_msg=f"after epoch bump, call {call}")
+        np.testing.assert_array_equal(D_t.cpu().numpy(), Do[24 * call:24 * call + 24], err_msg=f"after epoch bump, call {call}")
+    assert idx.stats()["graph_replays"] == 10               # re-captured + launched (not the stale exec), replayed twice
+    # a graph is dropped while its last launch may still be running: shape A twice (captured + launched), then shape B at
+    # once on the same stream, no synchronisation in between (the exec is destroyed only behind its launch's event)
+    D7_t = torch.empty((7, 10), dtype=torch.float32, device=dev)
+    I7_t = torch.empty((7, 10), dtype=torch.int64, device=dev)
+    with torch.cuda.stream(side):
+        q_t.copy_(torch.from_numpy(Q[:24]))
+    side.synchronize()
+    for _ in range(4):
+        idx.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        idx.search_device(q_t.data_ptr(), 24, 10, D_t.data_ptr(), I_t.data_ptr(), side.cuda_stream)
+        idx.search_device(q_t.data_ptr(), 7, 10, D7_t.data_ptr(), I7_t.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    np.testing.assert_array_equal(I_t.cpu().numpy(), Io[:24])
+    np.testing.assert_array_equal(I7_t.cpu().numpy(), Io[:7])
+    np.testing.assert_array_equal(D7_t.cpu().numpy(), Do[:7])
     idx.set_option("graph", 0)
     idx.close()
 

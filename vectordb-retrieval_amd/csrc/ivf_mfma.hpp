@@ -55,14 +55,16 @@ __global__ __launch_bounds__(256) void ivf_build_panels_kernel(const float *__re
     if (__any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
-__global__ __launch_bounds__(256) void ivf_build_bias_kernel(const float *__restrict__ xnorm2, int64_t nspans, int metric,
-                                                             const int32_t *__restrict__ span_row0,
+// (bias[i] belongs to local row i % span_rows of panel span i / span_rows: both panel layouts map their MFMA rows to
+//  local rows such that the accumulator init of a lane is a run of consecutive floats)
+__global__ __launch_bounds__(256) void ivf_build_bias_kernel(const float *__restrict__ xnorm2, int64_t nspans, int span_rows,
+                                                             int metric, const int32_t *__restrict__ span_row0,
                                                              const int32_t *__restrict__ span_valid,
                                                              float *__restrict__ bias) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nspans * kSpanRows) return;
-    const int64_t span = i / kSpanRows;
-    const int local = (int)(i - span * kSpanRows);
+    if (i >= nspans * span_rows) return;
+    const int64_t span = i / span_rows;
+    const int local = (int)(i - span * span_rows);
     bias[i] = (local < span_valid[span]) ? (metric == 0 ? xnorm2[span_row0[span] + local] : 0.f) : kPadBias;
 }
 
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restric
 // Lists are handled 1024 at a time with a block-wide exclusive scan of (groups, bins).
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cnt,
                                                         const int32_t *__restrict__ list_pspan0, int nlist, int group,
-                                                        int bps, int max_items, int max_slots, int max_bins,
+                                                        int bins_per_span, int max_items, int max_slots, int max_bins,
                                                         int32_t *__restrict__ slot_off, int32_t *__restrict__ list_item0,
                                                         int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
                                                         int32_t *__restrict__ item_bin0, IvfPlan *plan,
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
             if (c > 0) atomicAdd(&s_rows, (unsigned long long)c * (unsigned long long)(offsets[l + 1] - offsets[l]));
             if (c > 0 && spans > 0) {
                 g = (c + group - 1) / group;
-                bins_per_item = spans * 2 * bps;
+                bins_per_item = spans * bins_per_span;
             }
         }
         s_g[tid] = g;
@@ -298,7 +300,8 @@ struct IvfSelectArgs {
     int64_t nq;
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
     int probe_cap;                // nprobe rounded up to 64: size of the per-probe LDS arrays
-    int bt, bps;                  // tiles per bin, bins per (span, lane half)
+    int bins_per_span, bin_rows;  // level-1 bins of a panel span (entry e of a list = bin e % bins_per_span of its span
+                                  // e / bins_per_span) and rows per bin: bin b covers local rows [b bin_rows, (b + 1) bin_rows)
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
 };
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 if (l >= 0 && slot >= 0) {
                     const int rel = slot - a.slot_off[l];
                     const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
-                    nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * 2 * a.bps;
+                    nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * a.bins_per_span;
                     base = (size_t)a.item_bin0[item] * a.group + (size_t)col * nb;
                     lst = (int)l;
                 }
@@ -417,10 +420,10 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     const int l = p_list[p];
                     const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
                     const float m2 = a.bin_m2[base + ei];
-                    const int span_local = ei / (2 * a.bps), hh = (ei / a.bps) & 1, bt = ei % a.bps;
+                    const int span_local = ei / a.bins_per_span, bin = ei % a.bins_per_span;
                     const int pspan = a.list_pspan0[l] + span_local;
-                    row0 = a.span_row0[pspan] + hh * kBinRows + bt * (a.bt * 16);
-                    row1 = row0 + a.bt * 16;
+                    row0 = a.span_row0[pspan] + bin * a.bin_rows;
+                    row1 = row0 + a.bin_rows;
                     const int end = a.span_row0[pspan] + a.span_valid[pspan];
                     if (row1 > end) row1 = end;
                     c1 = true;

@@ -229,11 +229,14 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         // (returning forms, results consumed below: a returned atomic has been performed at the coherence point)
         unsigned seen = 0;
         const unsigned ab = __float_as_uint(fabsf(amax));
-        if (ab > *reinterpret_cast<volatile unsigned *>(&info->absmax_bits)) seen += atomicMax(&info->absmax_bits, ab);
-        if ((flags & 1) && *reinterpret_cast<volatile int *>(&info->nonfinite) == 0) seen += (unsigned)atomicOr(&info->nonfinite, 1);
-        if ((flags & 2) && *reinterpret_cast<volatile int *>(&info->not_integer) == 0) seen += (unsigned)atomicOr(&info->not_integer, 1);
-        if ((flags & 6) && *reinterpret_cast<volatile int *>(&info->not_u8) == 0) seen += (unsigned)atomicOr(&info->not_u8, 1);
-        if ((flags & 10) && *reinterpret_cast<volatile int *>(&info->not_s8) == 0) seen += (unsigned)atomicOr(&info->not_s8, 1);
+        // (pre-checks: relaxed agent-scope atomic loads -- a stale 0 only costs the atomic it would have skipped)
+        auto peek_u = [](unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto peek_i = [](int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        if (ab > peek_u(&info->absmax_bits)) seen += atomicMax(&info->absmax_bits, ab);
+        if ((flags & 1) && peek_i(&info->nonfinite) == 0) seen += (unsigned)atomicOr(&info->nonfinite, 1);
+        if ((flags & 2) && peek_i(&info->not_integer) == 0) seen += (unsigned)atomicOr(&info->not_integer, 1);
+        if ((flags & 6) && peek_i(&info->not_u8) == 0) seen += (unsigned)atomicOr(&info->not_u8, 1);
+        if ((flags & 10) && peek_i(&info->not_s8) == 0) seen += (unsigned)atomicOr(&info->not_s8, 1);
         asm volatile("" ::"v"(seen));
         // The workgroup that arrives last fixes the scales: no separate one-thread kernel (a ~5 us dispatch) between the
         // statistics and their consumers.  Every contribution is an agent-scope atomic (performed at the coherence point,
@@ -241,7 +244,12 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
         // thread's own atomics (vmcnt) before the counter bump orders them -- a __threadfence() here writes back the whole
         // L2 and cost 3-7 us per workgroup (MI355X_MICROARCH.md, "Valid forms": agent atomics on both sides).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(&info->done_blocks, 1u) == gridDim.x - 1) query_finalize(info, fin);
+        if (atomicAdd(&info->done_blocks, 1u) == gridDim.x - 1) {
+            // acquire side of the arrival counter: the statistics loads of query_finalize may not be hoisted above the
+            // counter bump (an agent-scope acquire fence only invalidates; it does not force the L2 write-back avoided above)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            query_finalize(info, fin);
+        }
     }
 }
 

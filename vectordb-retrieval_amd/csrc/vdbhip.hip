@@ -18,6 +18,7 @@
 #include "scan_i8.hpp"
 #include "ivf.hpp"
 #include "ivf_mfma.hpp"
+#include "ivf_kloop.hpp"
 #include "dense.hpp"
 
 using namespace vdb;
@@ -126,6 +127,7 @@ struct vdb_index_s {
         }
     } graph_key, graph_warm;
     hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t graph_ev = nullptr;           // recorded behind every launch of graph_exec (graph_drop_exec waits for it)
     uint64_t graph_epoch = 0;                // g_alloc_epoch when the graph was captured
     int64_t graph_replays = 0;
     int small_batch_off = 0;                 // option "small_batch" = 0: batches <= 512 queries keep the batch-shaped grid
@@ -167,6 +169,8 @@ struct vdb_index_s {
     size_t dbg_words = 0;                    // scan_variant 6: words of per-wave stamps left in ws.dense
     int64_t ivf_pspans = 0;
     int ivf_max_pspans = 0;
+    int ivf_span_rows = kSpanRows;           // rows per panel span: 512 (32-row tiles, D <= 128) or 16 * ivf_tps (p16, D > 128)
+    int ivf_tps = 0, ivf_tps_override = 0;   // p16 tiles per span of the IVF panel space (16 / 64); option "ivf_tps"
     DevBuf ivf_list_pspan0, ivf_span_row0, ivf_span_valid;
     DevBuf ivf_cnt /* per-list counts | cursors | slot -> query map: one buffer, one memset */, ivf_slot_off, ivf_list_item0,
         ivf_item_list, ivf_item_slot0, ivf_item_bin0, ivf_plan, ivf_slot_of;
@@ -496,6 +500,7 @@ int vdb_destroy(vdb_handle h) {
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
         for (auto b : all) b->release();
         graph_reset(h);
+        if (h->graph_ev) (void)hipEventDestroy(h->graph_ev);
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
         for (int i = 0; i < 2; ++i) {
@@ -802,6 +807,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_bt") {
             if (value != 0 && value != 4 && value != 16) throw Error(VDB_ERR_INVALID, "ivf_bt must be 0, 4 or 16");
             h->ivf_bt = (int)value;
+        } else if (k == "ivf_tps") {           // D > 128, next add: tiles per panel span (0 auto, 16 = 64-row bins, 64 = 256-row bins)
+            if (value != 0 && value != 16 && value != 64) throw Error(VDB_ERR_INVALID, "ivf_tps must be 0, 16 or 64");
+            h->ivf_tps_override = (int)value;
         } else if (k == "ivf_part") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "ivf_part must be 0 (auto) or 1..1024 spans");
             h->ivf_part = (int)value;
