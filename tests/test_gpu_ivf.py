@@ -370,3 +370,94 @@ def test_small_query_batches_and_row_parts_bit_exact(vdb, oracle, kind):
     np.testing.assert_array_equal(I, Io[:8])
     np.testing.assert_array_equal(D, Do[:8])
     idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# D > 128: the items-mode K-loop scan (csrc/ivf_kloop.hpp)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nlist,nq,k,metric,tps,nprobe", [
+    (100_000, 384, 100, 1000, 20, "cosine", 0, 32),    # the reference's committed msmarco IVF shape (see test below)
+    (30_000, 200, 64, 300, 10, "l2", 0, 8),            # D not a multiple of 64, L2
+    (40_000, 768, 50, 129, 10, "ip", 0, 10),           # 768 dims, a batch that leaves padding waves in its work items
+    (60_000, 256, 16, 200, 10, "l2", 64, 4),           # long lists on 1024-row spans (256-row bins)
+    (60_000, 256, 16, 200, 10, "ip", 16, 16),          # the same lists on 256-row spans, every list probed
+])
+def test_kloop_list_scan_bit_exact(vdb, oracle, n, d, nlist, nq, k, metric, tps, nprobe):
+    """IVF-Flat on embeddings-sized vectors: the list-major MFMA scan serves D > 128 (it used to stop at 128 dims and
+    leave 384 / 768-dim indexes to the exhaustive float64 list scan).  Result == brute force over the probed lists, bit
+    for bit, from the MFMA path (candidates > 0), equal to the exact list scan (force_path = 1), for both span sizes."""
+    X, Q = _data(n, d, nq, seed=n + d)
+    m = "ip" if metric == "cosine" else metric
+    if metric == "cosine":
+        X, Q = rs.safe_normalize(X), rs.safe_normalize(Q)
+    C = X[np.random.default_rng(d).choice(n, nlist, replace=False)].copy()
+    idx = vdb.IVFFlatIndex(d, nlist, m, 0)
+    idx.set_centroids(C)
+    if tps:
+        idx.set_option("ivf_tps", tps)
+    idx.add(X, id_base=5)
+    lor = idx.assignment()
+    np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, m))
+    idx.set_nprobe(nprobe)
+    D, I = idx.search(Q, k)
+    st = idx.stats()
+    Do, Io = oracle.ivf_search(X, C, lor, Q, k, nprobe, m, id_base=5)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert st["last_path_name"] == "ivf" and st["last_candidates"] > 0, st      # the MFMA path served the batch
+    assert st["last_fallback_queries"] <= nq // 20, st
+    assert st["last_rows_scanned"] > 0
+    idx.set_option("force_path", 1)
+    D1, I1 = idx.search(Q, k)
+    idx.set_option("force_path", 0)
+    np.testing.assert_array_equal(I1, I)
+    np.testing.assert_array_equal(D1, D)
+    # row parts of one span and whole lists give the same bins
+    for part in (1, 1024):
+        idx.set_option("ivf_part", part)
+        D2, I2 = idx.search(Q, k)
+        np.testing.assert_array_equal(I2, I, err_msg=f"ivf_part={part}")
+        np.testing.assert_array_equal(D2, D, err_msg=f"ivf_part={part}")
+    idx.set_option("ivf_part", 0)
+    # small batches (one partly filled work item per list) and a forced overflow of every work list
+    for nqs in (1, 7, 70):
+        Ds, Is = idx.search(Q[:nqs], k)
+        np.testing.assert_array_equal(Is, Io[:nqs], err_msg=f"nq={nqs}")
+        np.testing.assert_array_equal(Ds, Do[:nqs], err_msg=f"nq={nqs}")
+    idx.set_option("list_cap", 1)
+    Df, If = idx.search(Q[:64], k)
+    np.testing.assert_array_equal(If, Io[:64])
+    np.testing.assert_array_equal(Df, Do[:64])
+    assert idx.stats()["last_fallback_queries"] >= 48         # (a query with a single candidate row does not overflow)
+    idx.close()
+
+
+def test_msmarco_shaped_ivf_through_the_plugins(vdb, oracle):
+    """The reference's own IVF benchmark on embeddings (benchmark_results/benchmark_20260305_070532/msmarco/
+    ivf_flat_results.json: 100 000 x 384, cosine, FaissIVFIndexer IVF100,Flat + FaissSearcher nprobe 32, topk 20, 70
+    queries; modular.py:418-449, 536-548) through HipIVFIndexer + HipIVFSearcher with the library's own k-means: the
+    searcher's conventions (normalised queries, negated scores) over results that equal the CPU restatement of IVF-Flat
+    on the trained centroids, served by the MFMA list scan."""
+    rng = np.random.default_rng(384)
+    centres = rng.standard_normal((64, 384)).astype(np.float32)
+    X = (centres[rng.integers(0, 64, 100_000)] + 1.5 * rng.standard_normal((100_000, 384))).astype(np.float32)
+    Q = (centres[rng.integers(0, 64, 70)] + 1.5 * rng.standard_normal((70, 384))).astype(np.float32)
+    algo = vdb.CompositeAlgorithm(name="ivf_flat", dimension=384, metric="cosine",
+                                  indexer={"type": "HipIVFIndexer", "index_type": "IVF100,Flat", "metric": "cosine",
+                                           "nprobe": 10},
+                                  searcher={"type": "HipIVFSearcher", "metric": "cosine", "nprobe": 32})
+    algo.build_index(X)
+    d, i = algo.batch_search(Q, k=20)
+    index = algo.searcher.index
+    st = index.stats()
+    assert index.nprobe == 32 and st["last_path_name"] == "ivf" and st["last_candidates"] > 0, st
+    Xn, Qn = rs.safe_normalize(X), rs.safe_normalize(Q)
+    do, io = oracle.ivf_search(Xn, index.centroids(), index.assignment(), Qn, 20, 32, "ip")
+    np.testing.assert_array_equal(i, io)
+    np.testing.assert_array_equal(d, -do)
+    _, ie = oracle.knn(Xn, Qn, 20, "ip")
+    r10 = rs.recall_at_k(ie, i, 10)
+    print(f"msmarco-shaped IVF100,Flat nprobe 32: recall@10 vs exact {r10:.4f} (the reference reports 0.9529 on its MS MARCO subset)")
+    assert r10 > 0.85
+    d1, i1 = algo.search(Q[0], k=20)
+    np.testing.assert_array_equal(i1, io[0])

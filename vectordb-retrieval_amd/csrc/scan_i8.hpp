@@ -153,8 +153,15 @@ struct ScanI8Args {
     const signed char *qrows;    // [nq][32*KS] int8 query rows cq - q (B fragments are gathered from them)
     int part_spans;              // items mode: spans per row part (blockIdx.y), 0 = whole list (see ScanArgs)
     int abl_no_bins;             // -DVDB_ABLATIONS builds only (timing, WRONG results): skip the level-1 bin stores
+    unsigned long long *dbg;     // DBG builds (-DVDB_ABLATIONS): per wave {head, mfma, select, tail, barrier, total} shader
+                                 // cycles, the s_memrealtime ticks of the same span, (stages << 1) | late
 };
 
+// a "use" of the accumulators that makes hipcc wait for the matrix pipe.  In a device-only function: the same asm written
+// inside the __global__ body makes the HOST pass drop the kernel's launch stub without a diagnostic (the "v" constraint on
+// an int16v is not a valid x86 operand, and in a template the failure is a silent substitution failure)
+__device__ __forceinline__ void wait_for_mfma(const int16v &acc) { asm volatile("s_nop 0" ::"v"(acc)); }
+__device__ __forceinline__ unsigned long long realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }   // v_med3_i32
@@ -209,7 +216,9 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // runs MFMA(t) then select(t), the late half select(t-1) then MFMA(t).  BT: tiles per level-1 bin; ITEMS: IVF work-item
 // mode (one inverted list x one group of query slots, bins laid out [item][slot][bin], third minimum kept); G: rows per
 // select group (must match bit 2 of QueryBatchInfo.i8_mode, which the select and refine kernels read).
-template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8>
+// DBG (diagnostic build, -DVDB_ABLATIONS only): in-kernel cycle stamps around the phases of every stage (results stay
+// exact; the stamped kernel is ~10 % slower) -- scripts/stamp_scan_i8.py.
+template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false>
 __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
@@ -400,6 +409,25 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
 
     int4v fr[KS];
     int16v cin, acc[CB];
+    // DBG: cycle sums per phase; tick(x) charges the cycles since the previous stamp to x.  `done` makes the MFMA results
+    // "used" so that the stamp behind an MFMA phase waits for the matrix pipe, not just for the issue.
+    unsigned long long c_head = 0, c_mfma = 0, c_sel = 0, c_tail = 0, c_bar = 0, t_last = 0, t_first = 0, r_first = 0;
+#define tick(bucket)                                   \
+    do {                                               \
+        if (DBG) {                                     \
+            const unsigned long long t__ = stamp();    \
+            bucket += t__ - t_last;                    \
+            t_last = t__;                              \
+        }                                              \
+    } while (0)
+#define done()                          \
+    do {                                \
+        if (DBG) { _Pragma("unroll") for (int cb__ = 0; cb__ < CB; ++cb__) wait_for_mfma(acc[cb__]); } \
+    } while (0)
+    if (DBG) {
+        t_first = t_last = stamp();
+        r_first = realtime_ticks();
+    }
     if (!late) {
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
@@ -408,18 +436,24 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
             read_phase_i8<KS>(A, B4, fr, cin, lane);
+            tick(c_head);
 #pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 __builtin_amdgcn_sched_barrier(0);
+                done();
+                tick(c_mfma);
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
                 select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) * GPT), m3);
+                tick(c_sel);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            tick(c_tail);
             __syncthreads();
+            tick(c_bar);
         }
     } else {
 #pragma unroll
@@ -432,6 +466,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             const int4v *A = lds_a(buf);
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
+            tick(c_head);
 #pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -440,15 +475,28 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((tp % BT) * GPT), m3);
                 if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
+                tick(c_sel);
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
+                done();
+                tick(c_mfma);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            tick(c_tail);
             __syncthreads();
+            tick(c_bar);
         }
         select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((BT - 1) * GPT), m3);
         flush_bin(span1 - 1, BPS - 1);
     }
+    if (DBG && a.dbg && lane == 0) {
+        const unsigned long long t_end = stamp(), r_end = realtime_ticks();
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+        d[0] = c_head; d[1] = c_mfma; d[2] = c_sel; d[3] = c_tail; d[4] = c_bar; d[5] = t_end - t_first;
+        d[6] = r_end - r_first; d[7] = ((unsigned long long)nstages << 1) | (late ? 1ull : 0ull);
+    }
+#undef tick
+#undef done
     if (ITEMS) return;
 
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + q0 + (lane & 31);

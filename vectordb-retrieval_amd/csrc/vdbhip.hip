@@ -827,7 +827,7 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
             h->i8_group = (int)value;
         } else if (k == "i8_variant") {
 #ifdef VDB_ABLATIONS
-            if (value < 0 || (((int)value) & 7) > 5 || value > 13) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5 (+8)");
+            if (value < 0 || (((int)value) & 7) > 5 || value > 19) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5 (+8, +16)");
 #else
             if (value < 0 || value > 5) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5");
 #endif
