@@ -69,7 +69,7 @@ WORKLOADS = {
     # BASELINE configs[3]: IVF-Flat over the sift1m data, nlist = 1024, --nprobe 8 / 32 / 128
     "ivf1024": (1_000_000, 128, 10_000, 10, "l2", "sift_like"),
     # the reference's committed IVF-on-embeddings benchmark shape (msmarco subset): cosine = normalise + ip
-    "msmarco_ivf": (100_000, 384, 10_000, 20, "ip", "unit_gaussian"),
+    "msmarco_ivf": (100_000, 384, 10_000, 20, "ip", "embedding_like"),
 }
 DEVICE_BLOCK_ROWS = 500_000
 
@@ -175,6 +175,24 @@ def real_sift():
     return None
 
 
+def embedding_like(n: int, nq: int, d: int, seed_x: int, seed_q: int, latent: int = 32, topics: int = 64):
+    """Sentence-embedding shaped unit vectors: the rows live near a `latent`-dimensional subspace of R^d (a fixed random
+    map of a topic centre + latent Gaussian, plus a little isotropic noise), so neighbour distances spread the way they do
+    in real embedding sets -- i.i.d. Gaussian rows in 384 dimensions would put every row at the same distance from every
+    query (distance concentration), which no embedding model produces."""
+    basis = np.random.default_rng(97).standard_normal((latent, d)).astype(np.float32) / np.sqrt(latent)
+    centres = np.random.default_rng(98).standard_normal((topics, latent)).astype(np.float32)
+
+    def rows(m, seed):
+        rng = np.random.default_rng(seed)
+        z = centres[rng.integers(0, topics, m)] + 0.8 * rng.standard_normal((m, latent), dtype=np.float32)
+        x = z @ basis + 0.05 * rng.standard_normal((m, d), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return np.ascontiguousarray(x, np.float32)
+
+    return rows(n, seed_x), rows(nq, seed_q)
+
+
 def make_data(name: str, rank: int):
     from vdbhip import datasets
 
@@ -191,14 +209,8 @@ def make_data(name: str, rank: int):
     elif gen == "glove_like":
         X = 0.5 * np.random.default_rng(50 + 7919 * rank).standard_normal((n, d), dtype=np.float32)
         Q = 0.5 * np.random.default_rng(51).standard_normal((nq, d), dtype=np.float32)
-    elif gen == "unit_gaussian":     # sentence-embedding shaped: a few dozen loose clusters on the unit sphere
-        rng = np.random.default_rng(384 + 7919 * rank)
-        centres = rng.standard_normal((64, d), dtype=np.float32)
-        X = centres[rng.integers(0, 64, n)] + 1.5 * rng.standard_normal((n, d), dtype=np.float32)
-        rq = np.random.default_rng(385)
-        Q = centres[rq.integers(0, 64, nq)] + 1.5 * rq.standard_normal((nq, d), dtype=np.float32)
-        X /= np.linalg.norm(X, axis=1, keepdims=True)
-        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    elif gen == "embedding_like":
+        X, Q = embedding_like(n, nq, d, 384 + 7919 * rank, 385)
     else:
         X, Q = datasets.random_reference(d, n, nq, 42)
     return np.ascontiguousarray(X, np.float32), np.ascontiguousarray(Q, np.float32), k, metric

@@ -105,6 +105,101 @@ __global__ __launch_bounds__(256 * WPS, WPS) void loop32(const int4v *A, const i
     }
 }
 
+// ---- 32x32x32 with the scan's STAGING: the A tiles are not resident; every 8 tiles (32 KiB) a stage arrives by LDS-DMA
+// (global_load_lds_dwordx4, 4 pieces of 1 KiB per wave, source L2-resident) into the other half of a double buffer,
+// one workgroup barrier per stage.  SYNC 1: the barrier alone (tiles stay resident); SYNC 2: barrier + LDS-DMA;
+// SYNC 3: as 2, and the two halves of the workgroup run MFMA / select in opposite order with sched_barrier fences
+// (the production kernel's phase stagger).
+template <int CB, int SYNC, int G>
+__global__ __launch_bounds__(512, 2) void loop32s(const int4v *A, const int4v *B, int *out, unsigned long long *clk, int iters) {
+    constexpr int NT = 512, ST = 8, kStage = ST * 4 * 64;       // vectors per stage
+    __shared__ int4v lds[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * kStage; i += NT) lds[i] = A[i % kLdsVec];
+    int4v b[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b[cb][ks] = B[(((wave * CB + cb) * 4 + ks) % 128) * 64 + lane];
+    __syncthreads();
+    int m1[CB], m2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) m1[cb] = m2[cb] = 0x7fffffff;
+    const bool late = SYNC == 3 && wave >= 4;
+    int16v acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0x1fffffff;
+    auto select = [&](int t) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 16 / G; ++g) {
+                int q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
+                if (G == 8) q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+                fold(q, (unsigned)((t * (16 / G) + g) & 63), m1[cb], m2[cb]);
+            }
+    };
+    const Stamp s0 = stamp_now();
+    const int nstage = iters * (kLdsVec / kStage);
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (SYNC >= 2) {
+            const int4v *src = A + ((st + 1) % (kLdsVec / kStage)) * kStage;
+            int4v *dst = lds + (buf ^ 1) * kStage;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wave + i * 8;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(src + p * 64 + lane)),
+                    reinterpret_cast<__attribute__((address_space(3))) void *>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                    16, 0, 0);
+            }
+        }
+        const int4v *base = lds + (SYNC >= 2 ? buf * kStage : 0);
+#pragma unroll 1
+        for (int t = 0; t < ST; ++t) {
+            const int4v *bp = base + ((t * 37 + (lane >> 5) * 4) & 1023);
+            int16v cin;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int4v c = bp[g];
+                cin[4 * g] = c.x; cin[4 * g + 1] = c.y; cin[4 * g + 2] = c.z; cin[4 * g + 3] = c.w;
+            }
+            const int4v *a = base + t * 4 * 64 + lane;
+            int4v f[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = a[ks * 64];
+            if (late) {            // retire the previous tile first, then this tile's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                select(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[ks], b[cb][ks], ks == 0 ? cin : acc[cb], 0, 0, 0);
+            if (!late) {
+                if (SYNC == 3) __builtin_amdgcn_sched_barrier(0);
+                select(t);
+                if (SYNC == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (SYNC >= 1) __syncthreads();
+    }
+    const Stamp s1 = stamp_now();
+    int r = 0;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) r += m1[cb] + m2[cb] + acc[cb][5];
+    out[blockIdx.x * NT + tid] = r;
+    if (lane == 0) {
+        clk[((size_t)blockIdx.x * (NT / 64) + wave) * 2] = s1.cyc - s0.cyc;
+        clk[((size_t)blockIdx.x * (NT / 64) + wave) * 2 + 1] = s1.real - s0.real;
+    }
+}
+
 // ---- 16x16x64: CB column blocks of 16 queries; a tile = 16 rows x 128 dims = 2 fragments of 1 KiB --------------------
 // C/D layout: lane (col = lane & 15, g = lane >> 4) holds rows 4g..4g+3 -> one quad per (tile, column block).
 // G = 4: quad select per tile (2 + 3 VALU per 4 scores).  G = 8: octs over two consecutive tiles (7 VALU per 8 scores).
@@ -240,6 +335,11 @@ int main() {
         R32(4, 2, 1, 8, "octs")   R16(8, 2, 1, 8, "octs")
         R32(4, 1, 0, 4, "bare")   R16(8, 1, 0, 4, "bare")
         R32(4, 1, 1, 8, "octs")   R16(8, 1, 1, 8, "octs")
+#define R32S(SYNC, label) report("32x32x32", 128, 2, label, run(loop32s<4, SYNC, 8>, 512, dA, dB, dO, dC, nblk, iters, e0, e1));
+        R32S(0, "octs, loop32s")
+        R32S(1, "octs +barrier/8t")
+        R32S(2, "octs +bar +DMA")
+        R32S(3, "octs +bar+DMA+stag")
     }
     return 0;
 }

@@ -16,7 +16,9 @@ from bench import make_data
 X, Q, k, metric = make_data("sift1m", 0)
 idx = vdbhip.FlatIndex(X.shape[1], metric, 0); idx.add(X)
 D0, I0 = idx.search(Q, k)
-for variant, name in ((16 + 3, "scan_i8_kernel<4,8,4> (1024-query tiles, 8-tile stages: production)"), (16 + 1, "scan_i8_kernel<4,8,2> (512-query tiles)")):
+for variant, name in ((16 + 3, "scan_i8_kernel<4,8,4> (1024-query tiles, 8-tile stages)"),
+                      (16 + 6, "scan_i8_kernel<4,8,4> + a pacing s_barrier per tile (i8_variant 6)"),
+                      (16 + 1, "scan_i8_kernel<4,8,2> (512-query tiles)")):
     idx.set_option("i8_variant", variant)
     for _ in range(25):        # (the clock settles under back-to-back launches)
         D, I = idx.search(Q, k)
@@ -27,7 +29,7 @@ for variant, name in ((16 + 3, "scan_i8_kernel<4,8,4> (1024-query tiles, 8-tile 
     w = w[w[:, 5] > 0]
     late = (w[:, 7].astype(np.int64) & 1) == 1
     stages = (w[:, 7].astype(np.int64) >> 1).astype(np.float64)
-    cb = 4 if variant == 19 else 2
+    cb = 2 if variant == 17 else 4
     print(f"== {name}: {len(w)} waves, in-kernel clock {np.median(w[:,5] / w[:,6]) * 0.1:.3f} GHz (median; p10 {np.percentile(w[:,5]/w[:,6],10)*0.1:.3f}, p90 {np.percentile(w[:,5]/w[:,6],90)*0.1:.3f})")
     for label, sel in (("early half", ~late), ("late half", late)):
         v, st = w[sel], stages[sel]

@@ -11,7 +11,7 @@ import vdbhip
 from bench import make_data
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variants", default="0,1,2,3")
+ap.add_argument("--variants", default="3,6,7,1")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--option", default="i8_variant")

@@ -50,6 +50,88 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(IvfScanArgs a) {
     }
 }
 
+// ---- flagged queries of the list-major path: exact list scan, split over as many waves as the chip has to spare ------
+// The select flags a query whose work lists overflowed (or whose scales were unusable); how many there are is known
+// only on the device.  One wave per flagged query (the first version) left a single straggler walking all its probed
+// lists alone: 2.8 ms for 32 lists of 384-dim rows behind a 0.6 ms scan.  Here a fixed grid reads the count and cuts
+// every flagged query into S = min(waves / count, max_split) splits (wave s takes probes s, s + S, ...); the S partial
+// lists of a query are merged by whichever of its waves arrives LAST (agent-scope release / acquire around a per-query
+// arrival counter), so there is no merge dispatch, and with S = 1 (many flagged queries) a wave writes its result
+// directly.  Zero flagged queries: every wave returns after one load.
+struct IvfFallbackArgs {
+    RefineCommon c;
+    const int64_t *offsets;      // [nlist+1]
+    const int64_t *probes;       // [nq][nprobe]
+    int nprobe;
+    const int32_t *fb_list;      // [count] flagged queries (compacted by ivf_select_kernel)
+    const int32_t *fb_count;     // [1]
+    int max_split;               // <= nprobe
+    int64_t cap_units;           // capacity of the partial buffers in (query, split) units, >= the number of queries
+    double *pkeys;               // [cap_units][k]
+    int64_t *pids;
+    int32_t *done;               // [nq] arrival counters, zeroed per batch
+    float *D;                    // final rows, or (D == nullptr) per-shard partial rows
+    int64_t *I;
+    double *okeys;
+    int64_t *oids;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void ivf_fallback_kernel(IvfFallbackArgs a) {
+    const int64_t count = *a.fb_count;
+    if (count <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    int64_t S = waves / count;
+    if (S > a.max_split) S = a.max_split;
+    if (S > a.cap_units / count) S = a.cap_units / count;
+    if (S < 1) S = 1;
+    for (int64_t u = wave0; u < count * S; u += waves) {
+        const int64_t f = u / S;
+        const int split = (int)(u - f * S);
+        const int64_t q = a.fb_list[f];
+        const float *qptr = a.c.Q + (size_t)q * a.c.D4;
+        WaveTopK<KPL> tk;
+        tk.init(a.c.k);
+        for (int p = split; p < a.nprobe; p += (int)S) {
+            const int64_t l = a.probes[(size_t)q * a.nprobe + p];
+            if (l < 0) continue;
+            scan_rows<KPL>(tk, a.c, qptr, a.offsets[l], a.offsets[l + 1]);
+        }
+        const size_t oq = (size_t)q * a.c.k;
+        if (S == 1) {
+            if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
+            else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
+            continue;
+        }
+        write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.pkeys + (size_t)u * a.c.k, a.pids + (size_t)u * a.c.k);
+        __threadfence();                                    // release: this lane's partial rows before the arrival below
+        int last = 0;
+        if (lane == 0) last = atomicAdd(&a.done[f], 1) == (int)S - 1;
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (!last) continue;
+        __threadfence();                                    // acquire: the other waves' partial rows
+        tk.init(a.c.k);
+        const int total = (int)S * a.c.k;
+        const size_t o0 = (size_t)f * S * a.c.k;            // the S partial rows of query f are consecutive units
+        for (int base = 0; base < total; base += 64) {
+            const int i = base + lane;
+            bool valid = i < total;
+            uint64_t key = ~0ull;
+            int64_t id = -1;
+            if (valid) {
+                id = __builtin_nontemporal_load(a.pids + o0 + i);
+                key = sortable_u64(__builtin_nontemporal_load(a.pkeys + o0 + i));
+                valid = id >= 0;
+            }
+            tk.offer(key, id, valid);
+        }
+        if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
+        else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
+    }
+}
+
 // ---- CSR build: xperm[i] = x[perm[i]], ids[i] = id_base + perm[i] ------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ perm,
                                                           int64_t n, int D4, int64_t id_base, float *__restrict__ xperm,

@@ -17,20 +17,27 @@
 //   TPS = 16: 256-row spans, four 64-row bins  (lists of ~1000 rows: +13 % padding; many small bins per query)
 //   TPS = 64: 1024-row spans, four 256-row bins (long lists: 4x fewer select entries per probed row)
 // Per pass a wave owns 8 tiles x 4 column blocks (128 rows x 64 slots, 128 accumulator registers), TPS / 8 passes
-// complete the four bins of a span; bins keep (m1, m2, m3) as every items-mode scan (third-minimum guard, scan.hpp) and
-// leave in [item][slot][bin] order for ivf_select_kernel.  K-step pipeline, LDS ring and barrier placement are those of
+// complete the four bins of a span; bins keep their five smallest quad minima (kIvfKloopMinima below; the D <= 128 items-mode
+// scans keep three, scan.hpp) and leave in [item][slot][bin] order for ivf_select_kernel.  K-step pipeline, LDS ring and barrier placement are those of
 // scan16_kloop_kernel.
 #pragma once
 #include "scan16.hpp"
 
 namespace vdb {
 
+// Quad minima kept per bin.  The D <= 128 scans keep three (one v_med3 each per quad: their select is issue-bound); here the
+// select runs once per pass of D / 64 K-steps, so two more cost ~1 % -- and they matter: the near neighbours of a query sit
+// in one or two of its probed lists, i.e. several per 64-row bin, and a bin with more close quads than minima kept must be
+// re-scored whole (with three minima the msmarco-shaped leg re-scored 5.8 bins = 370 rows of 1.5 KB per query, 70 % of
+// its time; with five a bin yields up to four candidate quads before it has to be re-scanned).
+constexpr int kIvfKloopMinima = 5;
+
 struct IvfKloopArgs {
     const half8 *panels;         // [pspans * TPS tiles][KS][64]
     const float *bias;           // [pspans * TPS * 16] linear in the local row of the span; kPadBias on padding rows
     const _Float16 *qrows;       // [nq][32 * KS] scaled fp16 query rows
     const QueryBatchInfo *info;
-    float *bin_m1, *bin_m2, *bin_m3;
+    float *bin_m[kIvfKloopMinima];   // the NM smallest quad minima of every bin, each with its quad id
     const int32_t *item_list, *item_slot0, *item_bin0, *n_items, *list_pspan0, *slot_query;
     int part_spans;              // spans per row part (blockIdx.y), 0 = whole list
     int ksteps;                  // 16-dim k-steps of the index (multiple of 4)
@@ -115,9 +122,12 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
     asm volatile("" : "+v"(NEG_INF));
     unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));
-    float m1[CB], m2[CB], m3[CB];
+    constexpr int NM = kIvfKloopMinima;
+    float m[NM][CB];           // m[0] <= m[1] <= ... : sorted insertion by one v_min + (NM - 1) v_med3 per quad
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) m1[cb] = m2[cb] = m3[cb] = INF;
+    for (int i = 0; i < NM; ++i)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) m[i][cb] = INF;
 
     float4v acc[HT][CB];
     half8 bq[CB][2];          // B fragments of the current K-step, reloaded in place (see scan_kloop_kernel)
@@ -187,9 +197,9 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                 const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
                                           fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
                 const float v = pack_score(qm, idmask, id);
-                m3[cb] = __builtin_amdgcn_fmed3f(m2[cb], m3[cb], v);
-                m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
-                m1[cb] = fast_min(m1[cb], v, NEG_INF);
+#pragma unroll
+                for (int i = NM - 1; i > 0; --i) m[i][cb] = __builtin_amdgcn_fmed3f(m[i - 1][cb], m[i][cb], v);
+                m[0][cb] = fast_min(m[0][cb], v, NEG_INF);
             }
         }
         if (slice == PPS - 1) {                              // the four bins (span, g) are complete: [item][slot][bin]
@@ -197,10 +207,11 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
             for (int cb = 0; cb < CB; ++cb) {
                 const size_t o = bin_base * kIvfKloopGroup + (size_t)(wave * 64 + cb * 16 + (lane & 15)) * nb_item +
                                  (size_t)((span - lspan0) * 4 + g);
-                a.bin_m1[o] = m1[cb];
-                a.bin_m2[o] = m2[cb];
-                a.bin_m3[o] = m3[cb];
-                m1[cb] = m2[cb] = m3[cb] = INF;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    a.bin_m[i][o] = m[i][cb];
+                    m[i][cb] = INF;
+                }
             }
         }
     }

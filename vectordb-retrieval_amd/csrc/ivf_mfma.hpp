@@ -289,8 +289,10 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(IvfPrepArgs a) {
 }
 
 // ---- select over the bins of a query's probed lists ----------------------------------------------------
+constexpr int kIvfMaxMinima = 5;
 struct IvfSelectArgs {
-    const float *bin_m1, *bin_m2, *bin_m3;
+    const float *bin_m[kIvfMaxMinima];   // the nm smallest quad minima of every bin (3: scan_kernel / scan_i8_kernel items mode,
+    int nm;                              // 5: ivf_kloop_scan_kernel), ascending, each carrying its quad id
     const float *eps;
     const QueryBatchInfo *info;
     const IvfPlan *plan;
@@ -303,6 +305,7 @@ struct IvfSelectArgs {
     int bins_per_span, bin_rows;  // level-1 bins of a panel span (entry e of a list = bin e % bins_per_span of its span
                                   // e / bins_per_span) and rows per bin: bin b covers local rows [b bin_rows, (b + 1) bin_rows)
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
+    int32_t *fb_list, *fb_count;  // flagged queries, compacted for ivf_fallback_kernel (ivf.hpp)
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
 };
 
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         for (int e = lane; e < E; e += 64) {
             const int p = probe_of(e);
             const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
-            const unsigned key = sortable_u32(a.bin_m1[base + (e - p_off[p])]);
+            const unsigned key = sortable_u32(a.bin_m[0][base + (e - p_off[p])]);
             vals[e] = key;
             low1 = min(low1, max(low0, key));
             low0 = min(low0, key);
@@ -408,49 +411,55 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
         for (int base_e = 0; base_e < E && !fb; base_e += 64) {
             const int e = base_e + lane;
-            // an active bin yields: its minimum quad; also its second quad when the second minimum is active but the
-            // third is not; a re-scan of the whole bin when three or more quads are active (or a quad would run past
-            // the end of its list)
-            bool c1 = false, c2 = false, resc = false;
-            int row0 = 0, row1 = 0, crow1 = 0, crow2 = 0;
+            // an active bin whose j smallest quad minima are active and whose (j + 1)-th is not yields those j quads; when
+            // all nm minima kept are active (more quads may be) the whole bin is re-scanned -- as it is when a quad would
+            // run past the end of its list
+            int ncq = 0;                       // candidate quads of this lane's entry
+            bool resc = false;
+            int row0 = 0, row1 = 0, crow[kIvfMaxMinima - 1] = {0, 0, 0, 0};
             if (e < E) {
                 const float m1 = unsortable_f32(vals[e]);
                 if (m1 <= that) {
                     const int p = probe_of(e), ei = e - p_off[p];
                     const int l = p_list[p];
                     const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
-                    const float m2 = a.bin_m2[base + ei];
+                    float mv[kIvfMaxMinima];
+                    mv[0] = m1;
+#pragma unroll
+                    for (int i = 1; i < kIvfMaxMinima; ++i) mv[i] = i < a.nm ? a.bin_m[i][base + ei] : __builtin_inff();
                     const int span_local = ei / a.bins_per_span, bin = ei % a.bins_per_span;
                     const int pspan = a.list_pspan0[l] + span_local;
                     row0 = a.span_row0[pspan] + bin * a.bin_rows;
                     row1 = row0 + a.bin_rows;
                     const int end = a.span_row0[pspan] + a.span_valid[pspan];
                     if (row1 > end) row1 = end;
-                    c1 = true;
-                    crow1 = row0 + cand_row_offset(__float_as_uint(m1), i8_mode);
-                    if (m2 <= that) {
-                        if (a.bin_m3[base + ei] <= that) {
-                            resc = true;
-                        } else {
-                            c2 = true;
-                            crow2 = row0 + cand_row_offset(__float_as_uint(m2), i8_mode);
-                        }
+                    int active = 0;            // (the minima ascend: the active ones are a prefix)
+#pragma unroll
+                    for (int i = 0; i < kIvfMaxMinima; ++i) active += (mv[i] <= that) ? 1 : 0;
+                    resc = active >= a.nm;
+                    ncq = resc ? 0 : active;
+#pragma unroll
+                    for (int i = 0; i < kIvfMaxMinima - 1; ++i) {
+                        crow[i] = row0 + cand_row_offset(__float_as_uint(mv[i]), i8_mode);
+                        if (i < ncq && crow[i] + grows > end) resc = true;
                     }
-                    if (resc || crow1 + grows > end || (c2 && crow2 + grows > end)) {
-                        c1 = c2 = false;
+                    if (resc) {
+                        ncq = 0;
                         resc = row1 > row0;
                     }
                 }
             }
-            const unsigned long long cm1 = __ballot(c1), cm2 = __ballot(c2), rm = __ballot(resc);
-            if (c1) {
-                const int pos = ncand + __popcll(cm1 & lt_mask);
-                if (pos < a.cand_cap) cr[pos] = crow1;
+#pragma unroll
+            for (int i = 0; i < kIvfMaxMinima - 1; ++i) {
+                const bool ci = ncq > i;
+                const unsigned long long cm = __ballot(ci);
+                if (ci) {
+                    const int pos = ncand + __popcll(cm & lt_mask);
+                    if (pos < a.cand_cap) cr[pos] = crow[i];
+                }
+                ncand += __popcll(cm);
             }
-            if (c2) {
-                const int pos = ncand + __popcll(cm1) + __popcll(cm2 & lt_mask);
-                if (pos < a.cand_cap) cr[pos] = crow2;
-            }
+            const unsigned long long rm = __ballot(resc);
             if (resc) {
                 const int pos = nres + __popcll(rm & lt_mask);
                 if (pos < a.rescan_cap) {
@@ -458,7 +467,6 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     rr[2 * pos + 1] = row1;
                 }
             }
-            ncand += __popcll(cm1) + __popcll(cm2);
             nres += __popcll(rm);
         }
         if (ncand > a.cand_cap || nres > a.rescan_cap) fb = true;
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         a.counts[2 * q + 1] = fb ? 0 : nres;
         a.fallback[q] = fb ? 1 : 0;
         if (fb) {
+            a.fb_list[atomicAdd(a.fb_count, 1)] = (int)q;
             stat_add(a.stat_counters, q, 2, 1ull);
         } else {
             stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);

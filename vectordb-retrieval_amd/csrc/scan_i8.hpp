@@ -177,9 +177,14 @@ __device__ __forceinline__ void select_phase_i8(const int16v (&acc)[CB], int (&m
         const unsigned idg = (unsigned)__builtin_amdgcn_readfirstlane((int)(id0 + g));
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            int q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
-            if (G == 8)
-                q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+            int q;
+            if (G == 8) {      // three v_min3_i32 + one v_min_i32 (a balanced tree of two-operand minima compiles to 2 + 3)
+                const int t1 = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), acc[cb][G * g + 2]);
+                const int t2 = imin(imin(acc[cb][G * g + 3], acc[cb][G * g + 4]), acc[cb][G * g + 5]);
+                q = imin(imin(imin(acc[cb][G * g + 6], acc[cb][G * g + 7]), t1), t2);
+            } else {
+                q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
+            }
             const int v = (int)(((unsigned)q << 6) | idg);
             if (M3) m3[cb] = imed3(m2[cb], m3[cb], v);       // (items mode: third minimum, see scan.hpp select_phase)
             m2[cb] = imed3(m1[cb], m2[cb], v);
@@ -218,7 +223,12 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // select group (must match bit 2 of QueryBatchInfo.i8_mode, which the select and refine kernels read).
 // DBG (diagnostic build, -DVDB_ABLATIONS only): in-kernel cycle stamps around the phases of every stage (results stay
 // exact; the stamped kernel is ~10 % slower) -- scripts/stamp_scan_i8.py.
-template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false>
+// TB (pacing barriers, 0 = none): an s_barrier every TB tiles inside a stage.  The stamps of the unpaced kernel
+// (profiles/r03_stamps_scan_i8.txt) show the early half of a workgroup running its 8 tiles in ~60 % of the stage and then
+// waiting at the stage barrier, while the late half -- which loses the pipe arbitration while both are active -- works
+// through alternating MFMA and select phases ALONE, i.e. with the matrix pipe idle during its selects.  A bare s_barrier
+// (no memory wait) per tile keeps the two waves of a SIMD in anti-phase: MFMA(t) of one beside select of the other.
+template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false, int TB = 0>
 __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
@@ -402,6 +412,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 stage_issue(st + 1, (st & 1) ^ 1);
                 stage_bias_store((st & 1) ^ 1);
             }
+            if (TB)
+                for (int t = 0; t + 1 < ST; ++t)
+                    if ((t + 1) % TB == 0) __builtin_amdgcn_s_barrier();
             __syncthreads();
         }
         return;
@@ -447,6 +460,11 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
                 select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) * GPT), m3);
                 tick(c_sel);
+                if (TB && (t + 1) % TB == 0 && t + 1 < ST) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    tick(c_bar);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);
@@ -479,6 +497,11 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 done();
                 tick(c_mfma);
+                if (TB && (t + 1) % TB == 0 && t + 1 < ST) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    tick(c_bar);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < nstages) stage_bias_store(buf ^ 1);

@@ -70,13 +70,13 @@ struct Workspace;
 inline QueryBatchInfo *batch_info(Workspace &ws);
 
 struct Workspace {
-    DevBuf qpad, qpanels, qpanels8, qrows8, info, eps, bin_m1, bin_m2, bin_m3, sb_m1, sb_m2, sb_span;
+    DevBuf qpad, qpanels, qpanels8, qrows8, info, eps, bin_m1, bin_m2, bin_m3, bin_m4, bin_m5, sb_m1, sb_m2, sb_span;
     DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
-        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
+        const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &bin_m4, &bin_m5, &sb_m1, &sb_m2, &sb_span, &cand,
                                &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
                                &stage_i, &dense};
         size_t s = 0;
@@ -84,7 +84,7 @@ struct Workspace {
         return s;
     }
     void release() {
-        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &sb_m1, &sb_m2, &sb_span, &cand,
+        DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &bin_m4, &bin_m5, &sb_m1, &sb_m2, &sb_span, &cand,
                          &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
                          &dense};
         for (auto b : all) b->release();
@@ -827,9 +827,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
             h->i8_group = (int)value;
         } else if (k == "i8_variant") {
 #ifdef VDB_ABLATIONS
-            if (value < 0 || (((int)value) & 7) > 5 || value > 19) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5 (+8, +16)");
+            if (value < 0 || value > 23) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..7 (+8, +16)");
 #else
-            if (value < 0 || value > 5) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..5");
+            if (value < 0 || value > 7) throw Error(VDB_ERR_INVALID, "i8_variant must be 0..7");
 #endif
             h->i8_variant = (int)value;
         } else if (k == "kloop_qgroup") {
