@@ -228,7 +228,15 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // waiting at the stage barrier, while the late half -- which loses the pipe arbitration while both are active -- works
 // through alternating MFMA and select phases ALONE, i.e. with the matrix pipe idle during its selects.  A bare s_barrier
 // (no memory wait) per tile keeps the two waves of a SIMD in anti-phase: MFMA(t) of one beside select of the other.
-template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false, int TB = 0>
+// RING: LDS stages of the staging ring.  2 = double buffer, one stage in flight beyond the one being computed: right for
+// the batch-shaped launch, where a stage carries thousands of MFMA cycles.  The serving-shaped launches (1 ... 4 waves per
+// workgroup, one query tile) and the IVF work items stream their panels once, and with ONE stage in flight per workgroup
+// the chip holds ~8 MB of requests: at ~2 us of HBM latency that is the 3.5 - 4 TB/s those scans ran at (PMC: 58 % of
+// the wave time parked in s_waitcnt).  RING > 2 keeps RING - 1 stages requested: the per-row accumulator inits travel by
+// LDS-DMA as well (no register staging), every wave issues the same number of requests per stage, and a stage is
+// awaited with s_waitcnt vmcnt((RING - 2) x requests per stage) + s_barrier instead of the vmcnt(0) of __syncthreads().
+template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false, int TB = 0,
+          int RING = 2>
 __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
@@ -241,11 +249,13 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     constexpr int UNR = (ST * CB <= 8) ? ST : 1;
     static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && kTilesPerSpan % BT == 0 && BT % ST == 0, "bad geometry");
     static_assert(!ITEMS || CB == 2, "items mode: 64 slots per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
+    static_assert(RING >= 2 && RING <= 8 && (RING == 2 || (TB == 0 && ST % 2 == 0)), "bad ring");
+    constexpr bool kDeep = RING > 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * (kStageVec * 16 + ST * 32 * 4)];
     const int mode = a.info->i8_mode;
     if (!mode) return;                                    // this batch is served by the fp16 scan
     auto lds_a = [&](int buf) { return reinterpret_cast<int4v *>(smem + buf * (kStageVec * 16)); };
-    auto lds_b = [&](int buf) { return reinterpret_cast<int *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
+    auto lds_b = [&](int buf) { return reinterpret_cast<int *>(smem + RING * kStageVec * 16 + buf * (ST * 32 * 4)); };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
 
     constexpr int kPieces = kStageVec / 64;
     static_assert(kPieces % NWAVES == 0, "pieces must divide over the waves");
+    constexpr int kBiasPieces = (ST / 2 + NWAVES - 1) / NWAVES;       // ring mode: bias requests per wave and stage
     int stage_b[kBiasLoads];
     auto stage_issue = [&](int st, int buf) {
         const int64_t span = span0 + st / SPS;
@@ -326,6 +337,21 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                     static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
                 16, 0, 0);
         }
+        if (kDeep) {        // accumulator inits of the stage: ST / 2 pieces of 64 ints (two tiles each), by LDS-DMA too; every
+                            // wave issues kBiasPieces of them (a piece requested twice lands twice with the same bytes)
+#pragma unroll
+            for (int i = 0; i < kBiasPieces; ++i) {
+                const int j = (wave + i * NWAVES) % (ST / 2);
+                const int t = 2 * j + (lane >> 5), hh = (lane >> 4) & 1, r = lane & 15;
+                const int32_t *g = bias + span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
+                    reinterpret_cast<__attribute__((address_space(3))) void *>(
+                        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_b(buf) + j * 64))),
+                    4, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kBiasLoads; ++i) {
             const int e = tid + i * NT;
@@ -336,9 +362,22 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         }
     };
     auto stage_bias_store = [&](int buf) {
+        if (kDeep) return;
 #pragma unroll
         for (int i = 0; i < kBiasLoads; ++i)
             if (tid + i * NT < ST * 32) lds_b(buf)[tid + i * NT] = stage_b[i];
+    };
+    // ring mode: stage `st` (clamped to the last one: past the end the last stage is requested again into a slot nobody
+    // reads, so that every stage boundary has the same number of requests behind it) and the wait for the OLDEST stage in
+    // flight.  vmcnt counts this wave's requests in issue order; other requests in between (bin stores, the items-mode
+    // gathers) only make the wait more conservative.
+    auto ring_issue = [&](int st) { stage_issue(st < nstages ? st : nstages - 1, st % RING); };
+    auto ring_wait = [&]() {
+        constexpr int kKeep = (RING - 2) * (kPieces / NWAVES + kBiasPieces);
+        static_assert(kKeep < 64, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKeep) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
     // ITEMS with 64-row bins (BPS = 4): the four bins of a span half leave as ONE 16-byte store per array (see scan_kernel)
     constexpr bool kVecBins = ITEMS && BPS == 4;
@@ -392,7 +431,12 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         }
     };
 
-    stage_issue(0, 0);
+    if (kDeep) {
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) ring_issue(s);
+    } else {
+        stage_issue(0, 0);
+    }
     if (ITEMS) {   // gather: lane (col = lane&31, k half = lane>>5) reads 16 bytes of its slot's int8 query row
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
@@ -404,17 +448,25 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         }
     }
     stage_bias_store(0);
-    __syncthreads();
+    if (kDeep) ring_wait();
+    else __syncthreads();
 
     if (!ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid) {   // every query column of this wave is padding: keep staging + barriers going
         for (int st = 0; st < nstages; ++st) {
+            if (kDeep) {
+                ring_issue(st + RING - 1);
+                ring_wait();
+                continue;
+            }
             if (st + 1 < nstages) {
                 stage_issue(st + 1, (st & 1) ^ 1);
                 stage_bias_store((st & 1) ^ 1);
             }
-            if (TB)
+            if (TB > 0) {
+                constexpr int kTb = TB > 0 ? TB : 1;
                 for (int t = 0; t + 1 < ST; ++t)
-                    if ((t + 1) % TB == 0) __builtin_amdgcn_s_barrier();
+                    if ((t + 1) % kTb == 0) __builtin_amdgcn_s_barrier();
+            }
             __syncthreads();
         }
         return;
@@ -443,8 +495,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     }
     if (!late) {
         for (int st = 0; st < nstages; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const int buf = kDeep ? st % RING : st & 1;
+            if (kDeep) ring_issue(st + RING - 1);
+            else if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
             const int4v *A = lds_a(buf);
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
@@ -460,7 +513,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 if (t + 1 < ST) read_phase_i8<KS>(A + (t + 1) * KS * 64, B4 + (t + 1) * 8, fr, cin, lane);
                 select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)(((ts0 + t) % BT) * GPT), m3);
                 tick(c_sel);
-                if (TB && (t + 1) % TB == 0 && t + 1 < ST) {
+                if (TB > 0 && (t + 1) % (TB > 0 ? TB : 1) == 0 && t + 1 < ST) {
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     tick(c_bar);
@@ -468,9 +521,10 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             }
             __builtin_amdgcn_sched_barrier(0);
             if (((ts0 + ST) % BT) == 0) flush_bin(span0 + st / SPS, (ts0 + ST) / BT - 1);
-            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            if (!kDeep && st + 1 < nstages) stage_bias_store(buf ^ 1);
             tick(c_tail);
-            __syncthreads();
+            if (kDeep) ring_wait();
+            else __syncthreads();
             tick(c_bar);
         }
     } else {
@@ -479,8 +533,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][r] = (int)(kI8Inf >> 6);   // dummy "previous tile": (x << 6) == "+inf", never wins
         for (int st = 0; st < nstages; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
+            const int buf = kDeep ? st % RING : st & 1;
+            if (kDeep) ring_issue(st + RING - 1);
+            else if (st + 1 < nstages) stage_issue(st + 1, buf ^ 1);
             const int4v *A = lds_a(buf);
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + h * 4;
             const int ts0 = (st % SPS) * ST;
@@ -497,16 +552,17 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
                 done();
                 tick(c_mfma);
-                if (TB && (t + 1) % TB == 0 && t + 1 < ST) {
+                if (TB > 0 && (t + 1) % (TB > 0 ? TB : 1) == 0 && t + 1 < ST) {
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     tick(c_bar);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (st + 1 < nstages) stage_bias_store(buf ^ 1);
+            if (!kDeep && st + 1 < nstages) stage_bias_store(buf ^ 1);
             tick(c_tail);
-            __syncthreads();
+            if (kDeep) ring_wait();
+            else __syncthreads();
             tick(c_bar);
         }
         select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((BT - 1) * GPT), m3);
