@@ -69,6 +69,9 @@ struct DenseSelectArgs {
     int64_t *I;
     double *pkeys;             // partial rows [nq][k]
     int64_t *pids;
+    int inline_fallback;       // register kernel: a query whose candidate list overflows (or whose scales are unusable) is
+                               // served at once by its own wave with the exhaustive exact scan of the <= 2048 rows, instead of
+                               // being queued for a separate exhaustive pass (one dependent dispatch less per search)
     int set_only;              // final mode, register kernel: the caller only uses the SET of the k nearest rows (IVF coarse
                                // quantizer: which lists to probe), so candidates that are certainly among them skip the
                                // float64 re-scoring (dense_select_reg_kernel).  I then holds the set in no particular
@@ -217,6 +220,19 @@ __global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_
     }
     if (ncand > a.cand_cap) fb = true;
     if (fb) {
+        if (a.inline_fallback) {
+            WaveTopK<KPL> tkf;
+            tkf.init(k);
+            scan_rows<KPL, 4>(tkf, a.c, a.c.Q + (size_t)q * a.c.D4, 0, a.c.N);
+            const size_t of = (size_t)q * k;
+            write_topk<KPL>(tkf, a.c.metric, a.D ? a.D + of : nullptr, a.I ? a.I + of : nullptr, a.pkeys ? a.pkeys + of : nullptr,
+                            a.pids ? a.pids + of : nullptr);
+            if (lane == 0) {
+                a.fallback[q] = 0;
+                stat_add(a.stat_counters, q, 2, 1ull);
+            }
+            return;
+        }
         if (lane == 0) {
             a.fallback[q] = 1;
             a.fb_list[atomicAdd(a.fb_count, 1)] = (int)q;

@@ -84,16 +84,15 @@ constexpr int kIvfPairsPerBlock = 4096;
 
 // PPB: (query, probe) pairs per workgroup -- kIvfPairsPerBlock for large batches (fewer global atomics per list), a
 // quarter of it when that would leave most CUs idle (80 000 pairs = 20 workgroups).
-template <int PPB>
-__global__ __launch_bounds__(256) void ivf_count_kernel(const int64_t *__restrict__ probes, int64_t n, int nlist,
-                                                        int32_t *__restrict__ cnt) {
-    extern __shared__ int ivf_hist[];
+// (a device function: the per-batch prep kernel below runs it in its last workgroups -- one dispatch instead of two)
+__device__ __forceinline__ void ivf_count_body(int block, int PPB, const int64_t *__restrict__ probes, int64_t n, int nlist,
+                                               int32_t *__restrict__ cnt, int *ivf_hist) {
     const bool use_lds = nlist <= kIvfLdsLists;
     if (use_lds) {
         for (int l = threadIdx.x; l < nlist; l += 256) ivf_hist[l] = 0;
         __syncthreads();
     }
-    const int64_t i0 = (int64_t)blockIdx.x * PPB;
+    const int64_t i0 = (int64_t)block * PPB;
     for (int j = threadIdx.x; j < PPB; j += 256) {
         const int64_t i = i0 + j;
         if (i >= n) break;
@@ -239,12 +238,131 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int64_t *__restr
     }
 }
 
+// Plan + scatter in ONE dispatch (nlist <= kIvfLdsLists): the plan is a prefix sum over the per-list counts -- a few
+// microseconds of work that used to be a one-workgroup kernel of its own between the count and the scatter, i.e. a whole
+// dependent dispatch on the critical path of every search.  Here EVERY scatter workgroup recomputes the slot prefix it needs
+// (nlist counts -> groups per list -> exclusive scan, in LDS), and workgroup 0 also writes the plan's tables (work items,
+// their bin blocks, the per-list offsets the select reads) and scalars.
+template <int PPB>
+__global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
+                                                               int nlist, const int32_t *__restrict__ cnt,
+                                                               const int32_t *__restrict__ list_pspan0, int group,
+                                                               int bins_per_span, int max_items, int max_slots, int max_bins,
+                                                               const int64_t *__restrict__ offsets,
+                                                               int32_t *__restrict__ slot_off_g, int32_t *__restrict__ list_item0,
+                                                               int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
+                                                               int32_t *__restrict__ item_bin0, IvfPlan *plan,
+                                                               int32_t *__restrict__ cursor, int32_t *__restrict__ slot_query,
+                                                               int32_t *__restrict__ slot_of) {
+    extern __shared__ int ivf_hist[];          // [nlist] local counts, then global bases | [nlist] first slot of every list
+    int *s_slot_off = ivf_hist + nlist;
+    __shared__ int s_part_g[256], s_part_b[256];
+    __shared__ unsigned long long s_rows;
+    const int tid = threadIdx.x;
+    const int per = (nlist + 255) / 256;       // lists per thread: a contiguous run
+    const int l0 = tid * per, l1 = min(nlist, l0 + per);
+    if (tid == 0) s_rows = 0;
+    int sum_g = 0, sum_b = 0;
+    unsigned long long rows = 0;
+    for (int l = l0; l < l1; ++l) {
+        const int c = cnt[l];
+        const int spans = list_pspan0[l + 1] - list_pspan0[l];
+        const int g = (c > 0 && spans > 0) ? (c + group - 1) / group : 0;
+        sum_g += g;
+        sum_b += g * spans * bins_per_span;
+        if (blockIdx.x == 0 && c > 0) rows += (unsigned long long)c * (unsigned long long)(offsets[l + 1] - offsets[l]);
+        ivf_hist[l] = 0;
+    }
+    s_part_g[tid] = sum_g;
+    s_part_b[tid] = sum_b;
+    __syncthreads();
+    if (blockIdx.x == 0 && rows) atomicAdd(&s_rows, rows);
+    for (int o = 1; o < 256; o <<= 1) {        // inclusive Hillis-Steele scan of the 256 partial sums
+        const int vg = tid >= o ? s_part_g[tid - o] : 0;
+        const int vb = tid >= o ? s_part_b[tid - o] : 0;
+        __syncthreads();
+        s_part_g[tid] += vg;
+        s_part_b[tid] += vb;
+        __syncthreads();
+    }
+    const int items = s_part_g[255], bins = s_part_b[255], slots = items * group;
+    const bool dead = slots > max_slots || bins > max_bins || items > max_items;
+    int item0 = s_part_g[tid] - sum_g, bin0 = s_part_b[tid] - sum_b;     // exclusive prefixes of this thread's run
+    for (int l = l0; l < l1; ++l) {
+        const int c = cnt[l];
+        const int spans = list_pspan0[l + 1] - list_pspan0[l];
+        const int g = (c > 0 && spans > 0) ? (c + group - 1) / group : 0;
+        s_slot_off[l] = item0 * group;
+        if (blockIdx.x == 0) {
+            slot_off_g[l] = item0 * group;
+            list_item0[l] = item0;
+            if (!dead)
+                for (int j = 0; j < g; ++j) {
+                    item_list[item0 + j] = l;
+                    item_slot0[item0 + j] = (item0 + j) * group;
+                    item_bin0[item0 + j] = bin0 + j * spans * bins_per_span;
+                }
+        }
+        item0 += g;
+        bin0 += g * spans * bins_per_span;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        slot_off_g[nlist] = slots;
+        list_item0[nlist] = items;
+        plan->n_items = dead ? 0 : items;
+        plan->n_slots = slots;
+        plan->n_bins = bins;
+        plan->overflow = dead ? 1 : 0;
+        plan->rows_scanned = s_rows;
+    }
+    // ---- scatter (as ivf_scatter_kernel, with the slot prefix from LDS) ----
+    const int64_t n = nq * nprobe;
+    const int64_t i0 = (int64_t)blockIdx.x * PPB;
+    constexpr int PER = PPB / 256;
+    int rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = i0 + tid + u * 256;
+        rank[u] = -1;
+        if (i < n && !dead) {
+            const int64_t l = probes[i];
+            if (l >= 0 && l < nlist && list_pspan0[l + 1] > list_pspan0[l]) rank[u] = atomicAdd(&ivf_hist[l], 1);
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < nlist; l += 256) {
+        const int c = ivf_hist[l];
+        ivf_hist[l] = c ? atomicAdd(&cursor[l], c) : 0;   // -> global base of this workgroup's run
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = i0 + tid + u * 256;
+        if (i >= n) continue;
+        int slot = -1;
+        if (rank[u] >= 0) {
+            const int64_t l = probes[i];
+            slot = s_slot_off[l] + rank[u] + ivf_hist[l];
+            slot_query[slot] = (int32_t)(i / nprobe) + 1;     // (0 = padding slot)
+        }
+        slot_of[i] = slot;
+    }
+}
+
 // One dispatch for what the list scan needs from the query batch: the scales (when the coarse search of this batch has
 // already taken the statistics of these queries: every workgroup finalises its own copy in LDS, workgroup 0 publishes
 // it for the kernels that follow), the per-query error bounds, and the query rows the list scan gathers its B fragments
 // from, [nq][Dpad]: scaled fp16, or int8 cq - q when the batch is on the int8 scan and q8 is given.  It replaces a
 // one-thread finalize kernel + query_eps_kernel + ivf_qrows_kernel (three dependent ~4.5 us dispatches).
 struct IvfPrepArgs {
+    // workgroups [0, n_eps_blocks): error bounds; [n_eps_blocks, n_eps_blocks + n_row_blocks): query rows; the rest: the
+    // per-list probe counts of the batch (ivf_count_body; dynamic LDS = nlist ints when nlist <= kIvfLdsLists)
+    const int64_t *probes;
+    int64_t npairs;
+    int nlist, ppb;
+    int32_t *cnt;
+    unsigned n_row_blocks;
     EpsArgs eps;                  // (eps.info is replaced by the workgroup's copy)
     const float *Q;
     int64_t nq;
@@ -257,7 +375,12 @@ struct IvfPrepArgs {
     unsigned n_eps_blocks;
 };
 __global__ __launch_bounds__(256) void ivf_prep_kernel(IvfPrepArgs a) {
+    extern __shared__ int ivf_hist[];
     __shared__ QueryBatchInfo s_info;
+    if (blockIdx.x >= a.n_eps_blocks + a.n_row_blocks) {      // (uniform per workgroup)
+        ivf_count_body((int)(blockIdx.x - a.n_eps_blocks - a.n_row_blocks), a.ppb, a.probes, a.npairs, a.nlist, a.cnt, ivf_hist);
+        return;
+    }
     const QueryBatchInfo *info = a.info;
     if (a.src) {
         if (threadIdx.x == 0) {

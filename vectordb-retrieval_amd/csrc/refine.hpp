@@ -99,7 +99,7 @@ __device__ __forceinline__ void exact_keys(const float *__restrict__ x, const fl
     for (int j = 0; j < QB; ++j) out[j] = sortable_u64(metric == 0 ? acc[j] : -acc[j]);
 }
 
-template <int KPL>
+template <int KPL, int U = 16>
 __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon &c, const float *qptr, int64_t row0,
                                           int64_t row1) {
     const int lane = threadIdx.x & 63;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon 
         const int64_t row = base + lane;
         const bool valid = row < row1;
         uint64_t key = ~0ull;
-        if (valid) key = exact_key(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
+        if (valid) key = exact_key<U>(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
         tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
     }
 }

@@ -35,8 +35,16 @@ std::atomic<uint64_t> g_alloc_epoch{0};
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;      // a view into another DevBuf's memory (borrow): never freed here, cannot grow
+    void borrow(void *ptr, size_t bytes) {
+        if (!borrowed) release();
+        p = ptr;
+        cap = bytes;
+        borrowed = true;
+    }
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
+        if (borrowed) throw Error(VDB_ERR_INVALID, "internal: a borrowed device buffer cannot grow");
         g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
         if (p) VDB_HIP(hipFree(p));
         p = nullptr;
@@ -47,12 +55,13 @@ struct DevBuf {
         cap = want;
     }
     void release() {
-        if (p) {
+        if (p && !borrowed) {
             g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
             (void)hipFree(p);
         }
         p = nullptr;
         cap = 0;
+        borrowed = false;
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
@@ -146,6 +155,8 @@ struct vdb_index_s {
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
     bool small_is_clean = false;             // ws.small was cleared for this call and no batch has used it yet
+    bool small_preset = false;               // coarse quantizer of an IVF index: the parent has just cleared ws.small (it lives in
+                                             // the parent's ivf_zero buffer) -- the next search_device_impl skips its own memset
     int64_t info_valid_nq = -1;              // queries whose statistics the last search_batch left in batch_info(ws) (-1: none)
     bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
     bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
@@ -173,7 +184,10 @@ struct vdb_index_s {
     int ivf_span_rows = kSpanRows;           // rows per panel span: 512 (32-row tiles, D <= 128) or 16 * ivf_tps (p16, D > 128)
     int ivf_tps = 0, ivf_tps_override = 0;   // p16 tiles per span of the IVF panel space (16 / 64); option "ivf_tps"
     DevBuf ivf_list_pspan0, ivf_span_row0, ivf_span_valid;
-    DevBuf ivf_cnt /* per-list counts | cursors | slot -> query map: one buffer, one memset */, ivf_slot_off, ivf_list_item0,
+    // everything an IVF search needs zeroed, in ONE buffer cleared by ONE memset per batch (each memset is a ~4 us dispatch
+    // of its own): [coarse quantizer's ws.small | this handle's ws.small | per-list counts | cursors | slot -> query map |
+    // arrival counters of the flagged-query pass].  Both ws.small are views into it (DevBuf::borrow).
+    DevBuf ivf_zero, ivf_slot_off, ivf_list_item0,
         ivf_item_list, ivf_item_slot0, ivf_item_bin0, ivf_plan, ivf_slot_of;
 };
 
@@ -497,7 +511,7 @@ int vdb_destroy(vdb_handle h) {
         (void)hipDeviceSynchronize();
         DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
-                         &h->ivf_cnt, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
+                         &h->ivf_zero, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
         for (auto b : all) b->release();
         graph_reset(h);
@@ -708,6 +722,17 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
         s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
                                      h->panels8.cap + h->bias8.cap + h->rows8.cap + h->rowstat8.cap + h->ws.bytes());
+        {   // IVF: the CSR arrays, the per-batch plan buffers and the coarse quantizer's own index and workspace
+            const DevBuf *ivf[] = {&h->ivf_offsets, &h->ivf_ids, &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0,
+                                   &h->ivf_span_row0, &h->ivf_span_valid, &h->ivf_zero, &h->ivf_slot_off, &h->ivf_list_item0,
+                                   &h->ivf_item_list, &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
+            for (auto b : ivf) s.bytes_resident += (int64_t)b->cap;
+            if (h->ivf_zero.cap) s.bytes_resident -= (int64_t)h->ws.small.cap;      // (a view into ivf_zero: counted once)
+            if (h->coarse)
+                s.bytes_resident += (int64_t)(h->coarse->x32.cap + h->coarse->xnorm2.cap + h->coarse->panels.cap +
+                                              h->coarse->bias.cap + h->coarse->ws.bytes() -
+                                              (h->coarse->ws.small.borrowed ? h->coarse->ws.small.cap : 0));
+        }
         s.has_i8_copy = h->i8_ok ? 1 : 0;
         s.upload_blocks = h->last_upload_blocks;
         s.graph_replays = h->graph_replays;
