@@ -682,7 +682,7 @@ def test_graph_replay_of_a_serving_loop_is_exact(vdb, oracle):
         side.synchronize()
         np.testing.assert_array_equal(I_t.cpu().numpy(), Io[24 * call:24 * call + 24], err_msg=f"after epoch bump, call {call}")
         np.testing.assert_array_equal(D_t.cpu().numpy(), Do[24 * call:24 * call + 24], err_msg=f"after epoch bump, call {call}")
-    assert idx.stats()["graph_replays"] == 10               # re-captured + launched (not the stale exec), replayed twice
+    assert idx.stats()["graph_replays"] == 9                # the stale exec is dropped: eager warm-up, re-captured + launched, replayed
     # a graph is dropped while its last launch may still be running: shape A twice (captured + launched), then shape B at
     # once on the same stream, no synchronisation in between (the exec is destroyed only behind its launch's event)
     D7_t = torch.empty((7, 10), dtype=torch.float32, device=dev)

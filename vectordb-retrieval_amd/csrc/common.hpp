@@ -28,6 +28,12 @@ constexpr int kTilesPerSpan = 16;
 constexpr int kTileRows16 = 16;
 constexpr int kSpanRows16 = 1024;
 constexpr int kTilesPerSpan16 = 64;
+// IVF panel space (D <= 128): every inverted list is padded to whole spans, so its spans are SMALLER -- 8 tiles = 256 rows,
+// each lane half walking 128 consecutive rows: k-means lists of ~750 rows then carry 2 % of padding instead of 36 %
+// (512-row spans padded the median list of the SIFT1M / nlist 1024 index from 752 to 1024 rows).  Same row mapping inside a
+// span as the flat layout with 16 -> kIvfTilesPerSpan tiles.
+constexpr int kIvfTilesPerSpan = 8;
+constexpr int kIvfSpanRows = kIvfTilesPerSpan * kTileRows;
 constexpr int kStageTiles = 4;      // tiles per LDS stage (128 MFMA rows)
 constexpr int kMaxKSteps = 8;       // register-resident query fragments: D <= 128
 constexpr float kPadBias = 1.0e38f; // accumulator init of padding rows (scan units): never selected

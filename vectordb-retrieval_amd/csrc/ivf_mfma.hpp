@@ -7,8 +7,8 @@
 // select over the bins of its probed lists nominates candidate rows / bins to re-scan, and the exact float64
 // refine kernel produces the final answer: the result is bit-identical to the exact list scan.
 //
-// Panel space: every list is padded to whole 512-row spans; span_row0 / span_valid map a panel span back to
-// the permuted row range it covers.
+// Panel space: every list is padded to whole spans of kIvfSpanRows = 256 rows (common.hpp); span_row0 / span_valid map a
+// panel span back to the permuted row range it covers.
 #pragma once
 #include "common.hpp"
 #include "prep.hpp"
@@ -34,9 +34,9 @@ __global__ __launch_bounds__(256) void ivf_build_panels_kernel(const float *__re
     if (tile < ntiles) {
         const int rho = lane & 31, kh = lane >> 5;
         const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
-        const int64_t span = tile / kTilesPerSpan;
-        const int t = (int)(tile - span * kTilesPerSpan);
-        const int local = h * kBinRows + t * 16 + r;
+        const int64_t span = tile / kIvfTilesPerSpan;
+        const int t = (int)(tile - span * kIvfTilesPerSpan);
+        const int local = h * (kIvfSpanRows / 2) + t * 16 + r;
         const bool valid = local < span_valid[span];
         const int64_t row = (int64_t)span_row0[span] + local;
         const int d0 = ks * 16 + kh * 8;

@@ -167,9 +167,11 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KSTEPS * 64;           // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
-    constexpr int SPS = kTilesPerSpan / ST;               // stages per span
-    constexpr int BPS = kTilesPerSpan / BT;               // level-1 bins per (span, lane half)
-    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && kTilesPerSpan % BT == 0 && BT % ST == 0, "bad geometry");
+    constexpr int TPS = ITEMS ? kIvfTilesPerSpan : kTilesPerSpan;   // tiles per span (IVF panel space: smaller spans, common.hpp)
+    constexpr int kSpanR = TPS * 32, kHalfR = TPS * 16;   // rows per span / per lane half of a span
+    constexpr int SPS = TPS / ST;                         // stages per span
+    constexpr int BPS = TPS / BT;                         // level-1 bins per (span, lane half)
+    static_assert(TPS % ST == 0 && ST >= 2 && TPS % BT == 0 && BT % ST == 0, "bad geometry");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
     auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     auto stage_issue = [&](int st, int buf) {
         const int64_t span = span0 + st / SPS;
         const int sq = st % SPS;
-        const half8 *src = a.panels + ((size_t)(span * kTilesPerSpan + sq * ST) * KSTEPS) * 64;
+        const half8 *src = a.panels + ((size_t)(span * TPS + sq * ST) * KSTEPS) * 64;
         half8 *dst = lds_a(buf);
 #pragma unroll
         for (int i = 0; i < kPieces / NWAVES; ++i) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (e < ST * 32) {
                 const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
                 // raw value only: touching it here would make hipcc drain vmcnt(0), i.e. wait for the DMA
-                stage_b[i] = a.bias[span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r];
+                stage_b[i] = a.bias[span * kSpanR + hh * kHalfR + (sq * ST + t) * 16 + r];
             }
         }
     };
@@ -280,20 +282,21 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (tid + i * NT < ST * 32)
                 lds_b(buf)[tid + i * NT] = (stage_b[i] >= 0.9e38f) ? kPadBias : stage_b[i] * cs;
     };
-    // ITEMS with 64-row bins (BPS = 4): the four bins of a span half are consecutive floats of the lane's slot, so they
-    // are collected in registers and stored as ONE 16-byte vector per array instead of four scattered 4-byte stores --
+    // ITEMS with 64-row bins (BPS = 2 in the 8-tile spans of the IVF panel space; 4 while they were 16-tile spans): the bins of
+    // a span half are consecutive floats of the lane's slot, so they are collected in registers and stored as ONE vector per
+    // array instead of scattered 4-byte stores --
     // in [item][slot][bin] order every lane writes its own line, and at one flush per 4 tiles those stores kept the
     // CU's address path busy three quarters of the time (the list scan at nprobe 8 ran as long as at nprobe 32).
-    constexpr bool kVecBins = ITEMS && BPS == 4;
-    float4 pend1[2], pend2[2], pend3[2];
+    constexpr bool kVecBins = ITEMS && BPS == 2;          // (8-tile spans: 64-row bins come two per span half)
+    float2 pend1[2], pend2[2], pend3[2];
     // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
     auto flush_bin = [&](int64_t span, int bt) {
         if (kVecBins) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                pend1[cb] = make_float4(pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]);
-                pend2[cb] = make_float4(pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]);
-                pend3[cb] = make_float4(pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]);
+                pend1[cb] = make_float2(pend1[cb].y, m1[cb]);
+                pend2[cb] = make_float2(pend2[cb].y, m2[cb]);
+                pend3[cb] = make_float2(pend3[cb].y, m3[cb]);
                 m1[cb] = INF;
                 m2[cb] = INF;
                 m3[cb] = INF;
@@ -302,9 +305,9 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    *reinterpret_cast<float4 *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
-                    *reinterpret_cast<float4 *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
-                    *reinterpret_cast<float4 *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
+                    *reinterpret_cast<float2 *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                    *reinterpret_cast<float2 *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                    *reinterpret_cast<float2 *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
                 }
             }
             return;
@@ -417,10 +420,10 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
                 // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
-                const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
+                const int tp = (ts0 + t + TPS - 1) % TPS;
                 select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2), m3);
                 if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
-                    flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
+                    flush_bin(span0 + (st * ST - 1) / TPS, tp / BT);
                 if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
                 if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
                 mfma_phase<KSTEPS, ABL>(fr, b0, b1, cin, acc0, acc1);

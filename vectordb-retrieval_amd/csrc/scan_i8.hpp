@@ -242,12 +242,14 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
-    constexpr int SPS = kTilesPerSpan / ST;
-    constexpr int BPS = kTilesPerSpan / BT;               // level-1 bins per (span, lane half)
+    constexpr int TPS = ITEMS ? kIvfTilesPerSpan : kTilesPerSpan;   // tiles per span (IVF panel space: smaller spans, common.hpp)
+    constexpr int kSpanR = TPS * 32, kHalfR = TPS * 16;   // rows per span / per lane half of a span
+    constexpr int SPS = TPS / ST;
+    constexpr int BPS = TPS / BT;                         // level-1 bins per (span, lane half)
     // tiles of a stage unrolled together: the whole stage for the baseline shape; wider shapes keep the tile loop
     // rolled (fully unrolled, hipcc keeps several tiles' fragments and bias registers alive and spills hundreds of VGPRs)
     constexpr int UNR = (ST * CB <= 8) ? ST : 1;
-    static_assert(kTilesPerSpan % ST == 0 && ST >= 2 && kTilesPerSpan % BT == 0 && BT % ST == 0, "bad geometry");
+    static_assert(TPS % ST == 0 && ST >= 2 && TPS % BT == 0 && BT % ST == 0, "bad geometry");
     static_assert(!ITEMS || CB == 2, "items mode: 64 slots per wave");
     static_assert(RING >= 2 && RING <= 8 && (RING == 2 || (TB == 0 && ST % 2 == 0)), "bad ring");
     constexpr bool kDeep = RING > 2;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     auto stage_issue = [&](int st, int buf) {
         const int64_t span = span0 + st / SPS;
         const int sq = st % SPS;
-        const int4v *src = a.panels + ((size_t)(span * kTilesPerSpan + sq * ST) * KS) * 64;
+        const int4v *src = a.panels + ((size_t)(span * TPS + sq * ST) * KS) * 64;
         int4v *dst = lds_a(buf);
 #pragma unroll
         for (int i = 0; i < kPieces / NWAVES; ++i) {
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             for (int i = 0; i < kBiasPieces; ++i) {
                 const int j = (wave + i * NWAVES) % (ST / 2);
                 const int t = 2 * j + (lane >> 5), hh = (lane >> 4) & 1, r = lane & 15;
-                const int32_t *g = bias + span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r;
+                const int32_t *g = bias + span * kSpanR + hh * kHalfR + (sq * ST + t) * 16 + r;
                 __builtin_amdgcn_global_load_lds(
                     reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
                     reinterpret_cast<__attribute__((address_space(3))) void *>(
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             const int e = tid + i * NT;
             if (e < ST * 32) {
                 const int t = e >> 5, hh = (e >> 4) & 1, r = e & 15;
-                stage_b[i] = bias[span * kSpanRows + hh * kBinRows + (sq * ST + t) * 16 + r];
+                stage_b[i] = bias[span * kSpanR + hh * kHalfR + (sq * ST + t) * 16 + r];
             }
         }
     };
@@ -379,17 +381,18 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // ITEMS with 64-row bins (BPS = 4): the four bins of a span half leave as ONE 16-byte store per array (see scan_kernel)
-    constexpr bool kVecBins = ITEMS && BPS == 4;
-    int4v pend1[CB], pend2[CB], pend3[CB];
+    // ITEMS with 64-row bins (BPS = 2): the two bins of a span half leave as ONE 8-byte store per array (see scan_kernel)
+    constexpr bool kVecBins = ITEMS && BPS == 2;
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    int2v pend1[CB], pend2[CB], pend3[CB];
     // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]; ITEMS: [item][slot][bin]
     auto flush_bin = [&](int64_t span, int bt) {
         if (kVecBins) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                pend1[cb] = int4v{pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]};
-                pend2[cb] = int4v{pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]};
-                pend3[cb] = int4v{pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]};
+                pend1[cb] = int2v{pend1[cb].y, m1[cb]};
+                pend2[cb] = int2v{pend2[cb].y, m2[cb]};
+                pend3[cb] = int2v{pend3[cb].y, m3[cb]};
                 m1[cb] = INF;
                 m2[cb] = INF;
                 m3[cb] = INF;
@@ -398,9 +401,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
                 const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    *reinterpret_cast<int4v *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
-                    *reinterpret_cast<int4v *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
-                    *reinterpret_cast<int4v *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
+                    *reinterpret_cast<int2v *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                    *reinterpret_cast<int2v *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                    *reinterpret_cast<int2v *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
                 }
             }
             return;
@@ -544,9 +547,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase_i8<KS>(A + t * KS * 64, B4 + t * 8, fr, cin, lane);
-                const int tp = (ts0 + t + kTilesPerSpan - 1) % kTilesPerSpan;
+                const int tp = (ts0 + t + TPS - 1) % TPS;
                 select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((tp % BT) * GPT), m3);
-                if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / kTilesPerSpan, tp / BT);
+                if (t == 0 && st > 0 && (ts0 % BT) == 0) flush_bin(span0 + (st * ST - 1) / TPS, tp / BT);
                 __builtin_amdgcn_sched_barrier(0);
                 tick(c_sel);
                 mfma_phase_i8<KS, CB>(fr, bq, cin, acc);
@@ -602,9 +605,9 @@ __global__ __launch_bounds__(256) void ivf_build_panels_i8_kernel(const float *_
     if (tile >= ntiles) return;
     const int rho = lane & 31, kh = lane >> 5;
     const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
-    const int64_t span = tile / kTilesPerSpan;
-    const int t = (int)(tile - span * kTilesPerSpan);
-    const int local = h * kBinRows + t * 16 + r;
+    const int64_t span = tile / kIvfTilesPerSpan;
+    const int t = (int)(tile - span * kIvfTilesPerSpan);
+    const int local = h * (kIvfSpanRows / 2) + t * 16 + r;
     const bool valid = local < span_valid[span];
     const int64_t row = (int64_t)span_row0[span] + local;
     const int d0 = ks * 32 + kh * 16;
@@ -624,16 +627,16 @@ __global__ __launch_bounds__(256) void ivf_build_panels_i8_kernel(const float *_
     panels[gid] = out;
 }
 
-// bias8[w][panel row] over the panel space (P spans of 512 rows); padding rows get kI8PadBias
+// bias8[w][panel row] over the panel space (P spans of kIvfSpanRows rows); padding rows get kI8PadBias
 __global__ __launch_bounds__(256) void ivf_build_bias_i8_kernel(const float *__restrict__ X, int64_t nspans, int D, int D4,
                                                                 int metric, const int32_t *__restrict__ span_row0,
                                                                 const int32_t *__restrict__ span_valid,
                                                                 int32_t *__restrict__ bias8, int *__restrict__ rowstat) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = nspans * kSpanRows;
+    const int64_t total = nspans * kIvfSpanRows;
     if (i >= total) return;
-    const int64_t span = i / kSpanRows;
-    const int local = (int)(i - span * kSpanRows);
+    const int64_t span = i / kIvfSpanRows;
+    const int local = (int)(i - span * kIvfSpanRows);
     if (local >= span_valid[span]) {
         bias8[i] = kI8PadBias;
         bias8[total + i] = kI8PadBias;
