@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void ivf_build_bias_kernel(const float *__rest
     bias[i] = (local < span_valid[span]) ? (metric == 0 ? xnorm2[span_row0[span] + local] : 0.f) : kPadBias;
 }
 
+// bins a probed list of `spans` panel spans contributes per query slot (and the stride between slots in the bin arrays)
+__host__ __device__ inline int ivf_bins_of_list(int spans, int bins_per_span, int run_groups) {
+    if (!run_groups) return spans * bins_per_span;
+    return run_groups * ((spans * (bins_per_span / run_groups) + 3) & ~3);
+}
+
 // ---- per batch: invert (query, probe) -> (list, slot) ---------------------------------------------------
 struct IvfPlan {          // device-resident scalars written by ivf_plan_kernel
     int32_t n_items;
@@ -112,7 +118,7 @@ __device__ __forceinline__ void ivf_count_body(int block, int PPB, const int64_t
 // Lists are handled 1024 at a time with a block-wide exclusive scan of (groups, bins).
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cnt,
                                                         const int32_t *__restrict__ list_pspan0, int nlist, int group,
-                                                        int bins_per_span, int max_items, int max_slots, int max_bins,
+                                                        int bins_per_span, int run_groups, int max_items, int max_slots, int max_bins,
                                                         int32_t *__restrict__ slot_off, int32_t *__restrict__ list_item0,
                                                         int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
                                                         int32_t *__restrict__ item_bin0, IvfPlan *plan,
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
             if (c > 0) atomicAdd(&s_rows, (unsigned long long)c * (unsigned long long)(offsets[l + 1] - offsets[l]));
             if (c > 0 && spans > 0) {
                 g = (c + group - 1) / group;
-                bins_per_item = spans * bins_per_span;
+                bins_per_item = ivf_bins_of_list(spans, bins_per_span, run_groups);
             }
         }
         s_g[tid] = g;
@@ -247,8 +253,8 @@ template <int PPB>
 __global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int64_t *__restrict__ probes, int64_t nq, int nprobe,
                                                                int nlist, const int32_t *__restrict__ cnt,
                                                                const int32_t *__restrict__ list_pspan0, int group,
-                                                               int bins_per_span, int max_items, int max_slots, int max_bins,
-                                                               const int64_t *__restrict__ offsets,
+                                                               int bins_per_span, int run_groups, int max_items, int max_slots,
+                                                               int max_bins, const int64_t *__restrict__ offsets,
                                                                int32_t *__restrict__ slot_off_g, int32_t *__restrict__ list_item0,
                                                                int32_t *__restrict__ item_list, int32_t *__restrict__ item_slot0,
                                                                int32_t *__restrict__ item_bin0, IvfPlan *plan,
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int64_t *__
         const int spans = list_pspan0[l + 1] - list_pspan0[l];
         const int g = (c > 0 && spans > 0) ? (c + group - 1) / group : 0;
         sum_g += g;
-        sum_b += g * spans * bins_per_span;
+        sum_b += g * ivf_bins_of_list(spans, bins_per_span, run_groups);
         if (blockIdx.x == 0 && c > 0) rows += (unsigned long long)c * (unsigned long long)(offsets[l + 1] - offsets[l]);
         ivf_hist[l] = 0;
     }
@@ -300,11 +306,11 @@ __global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int64_t *__
                 for (int j = 0; j < g; ++j) {
                     item_list[item0 + j] = l;
                     item_slot0[item0 + j] = (item0 + j) * group;
-                    item_bin0[item0 + j] = bin0 + j * spans * bins_per_span;
+                    item_bin0[item0 + j] = bin0 + j * ivf_bins_of_list(spans, bins_per_span, run_groups);
                 }
         }
         item0 += g;
-        bin0 += g * spans * bins_per_span;
+        bin0 += g * ivf_bins_of_list(spans, bins_per_span, run_groups);
     }
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0) {
@@ -424,9 +430,13 @@ struct IvfSelectArgs {
     const int32_t *slot_off, *list_item0, *item_bin0, *list_pspan0, *span_row0, *span_valid;
     int64_t nq;
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
+    int vals_entries;             // LDS entries per wave for the bin minima: max_entries when k > 64, else 0 (see the kernel)
     int probe_cap;                // nprobe rounded up to 64: size of the per-probe LDS arrays
-    int bins_per_span, bin_rows;  // level-1 bins of a panel span (entry e of a list = bin e % bins_per_span of its span
-                                  // e / bins_per_span) and rows per bin: bin b covers local rows [b bin_rows, (b + 1) bin_rows)
+    int bins_per_span, bin_rows;  // level-1 bins of a panel span and rows per bin: bin b of a span covers its local rows
+                                  // [b bin_rows, (b + 1) bin_rows).  Entry e of a probed list:
+    int run_groups;               //   0 (K-loop scan): [span][bin], e = span * bins_per_span + bin
+                                  //   2 (32-row-tile scans): one run per lane half, [half][span][bin of the half], every run
+                                  //   padded to a multiple of 4 entries (the padding holds +inf): see ivf_bins_of_list
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
     int32_t *fb_list, *fb_count;  // flagged queries, compacted for ivf_fallback_kernel (ivf.hpp)
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
@@ -447,8 +457,12 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
     // per wave: vals[max_entries] | p_off[probe_cap+32] | p_base lo/hi [2*probe_cap] | p_list[probe_cap] -- sized by
     // the launch (what this nprobe and the longest list can need), not by the compile-time maxima: the LDS footprint
     // is what limits how many queries a CU works on at once
-    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.max_entries + 4 * a.probe_cap + 64);
-    int *p_off = reinterpret_cast<int *>(vals + a.max_entries);
+    // (vals only for k > 64, whose threshold needs every bin minimum in LDS: a.vals_entries = max_entries, else 0 -- without
+    //  it a wave needs ~2 KB instead of ~18 KB and eight times as many queries are in flight per CU; the second pass then
+    //  re-reads the minima, L2-resident by now)
+    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.vals_entries + 4 * a.probe_cap + 64);
+    int *p_off = reinterpret_cast<int *>(vals + a.vals_entries);
+    const bool keep = a.vals_entries > 0;
     unsigned *p_base_lo = reinterpret_cast<unsigned *>(p_off + a.probe_cap + 32);
     unsigned *p_base_hi = p_base_lo + a.probe_cap;
     int *p_list = reinterpret_cast<int *>(p_base_hi + a.probe_cap);
@@ -466,7 +480,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 if (l >= 0 && slot >= 0) {
                     const int rel = slot - a.slot_off[l];
                     const int item = a.list_item0[l] + rel / a.group, col = rel % a.group;
-                    nb = (a.list_pspan0[l + 1] - a.list_pspan0[l]) * a.bins_per_span;
+                    nb = ivf_bins_of_list(a.list_pspan0[l + 1] - a.list_pspan0[l], a.bins_per_span, a.run_groups);
                     base = (size_t)a.item_bin0[item] * a.group + (size_t)col * nb;
                     lst = (int)l;
                 }
@@ -499,13 +513,30 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
     int ncand = 0, nres = 0;
     if (!fb) {
         unsigned low0 = 0xFFFFFFFFu, low1 = 0xFFFFFFFFu;     // the two smallest keys this lane has seen
-        for (int e = lane; e < E; e += 64) {
-            const int p = probe_of(e);
-            const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
-            const unsigned key = sortable_u32(a.bin_m[0][base + (e - p_off[p])]);
-            vals[e] = key;
-            low1 = min(low1, max(low0, key));
-            low0 = min(low0, key);
+        // (four entries per lane and round: their probe look-ups and loads overlap -- one entry per round left ONE global
+        //  load in flight per lane, and at nprobe 128 (2000+ entries per query) this loop ran as long as the list scan)
+        for (int e0 = lane; e0 < E; e0 += 256) {
+            float raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u;
+                raw[u] = __builtin_inff();
+                if (e < E) {
+                    const int p = probe_of(e);
+                    const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
+                    raw[u] = a.bin_m[0][base + (e - p_off[p])];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u;
+                if (e < E) {
+                    const unsigned key = sortable_u32(raw[u]);
+                    if (keep) vals[e] = key;
+                    low1 = min(low1, max(low0, key));
+                    low0 = min(low0, key);
+                }
+            }
         }
         unsigned ans = 0;
         if (a.k <= 64) {
@@ -532,8 +563,28 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         if (!(that < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
-        for (int base_e = 0; base_e < E && !fb; base_e += 64) {
-            const int e = base_e + lane;
+        for (int e4 = 0; e4 < E && !fb; e4 += 256) {
+          float m1v[4];
+          int pv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {      // the minima of four rounds of entries, requested together
+              const int e = e4 + 64 * u + lane;
+              m1v[u] = __builtin_inff();
+              pv[u] = 0;
+              if (e < E) {
+                  pv[u] = probe_of(e);
+                  if (keep) {
+                      m1v[u] = unsortable_f32(vals[e]);
+                  } else {
+                      const size_t base = ((size_t)p_base_hi[pv[u]] << 32) | p_base_lo[pv[u]];
+                      m1v[u] = a.bin_m[0][base + (e - p_off[pv[u]])];
+                  }
+              }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e4 + 64 * u + lane;
+            if (e4 + 64 * u >= E) break;
             // an active bin whose j smallest quad minima are active and whose (j + 1)-th is not yields those j quads; when
             // all nm minima kept are active (more quads may be) the whole bin is re-scanned -- as it is when a quad would
             // run past the end of its list
@@ -541,16 +592,26 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
             bool resc = false;
             int row0 = 0, row1 = 0, crow[kIvfMaxMinima - 1] = {0, 0, 0, 0};
             if (e < E) {
-                const float m1 = unsortable_f32(vals[e]);
+                const float m1 = m1v[u];
                 if (m1 <= that) {
-                    const int p = probe_of(e), ei = e - p_off[p];
+                    const int p = pv[u], ei = e - p_off[p];
                     const int l = p_list[p];
                     const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
                     float mv[kIvfMaxMinima];
                     mv[0] = m1;
 #pragma unroll
                     for (int i = 1; i < kIvfMaxMinima; ++i) mv[i] = i < a.nm ? a.bin_m[i][base + ei] : __builtin_inff();
-                    const int span_local = ei / a.bins_per_span, bin = ei % a.bins_per_span;
+                    int span_local, bin;
+                    if (a.run_groups) {      // (an active entry is never run padding: that holds +inf)
+                        const int bpg = a.bins_per_span / a.run_groups;            // bins of a span in one run
+                        const int run_len = ((a.list_pspan0[l + 1] - a.list_pspan0[l]) * bpg + 3) & ~3;
+                        const int grp = ei / run_len, r = ei - grp * run_len;
+                        span_local = r / bpg;
+                        bin = grp * bpg + (r - span_local * bpg);
+                    } else {
+                        span_local = ei / a.bins_per_span;
+                        bin = ei - span_local * a.bins_per_span;
+                    }
                     const int pspan = a.list_pspan0[l] + span_local;
                     row0 = a.span_row0[pspan] + bin * a.bin_rows;
                     row1 = row0 + a.bin_rows;
@@ -591,6 +652,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 }
             }
             nres += __popcll(rm);
+          }
         }
         if (ncand > a.cand_cap || nres > a.rescan_cap) fb = true;
     }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
     }
 
     const int nstages = (int)(span1 - span0) * SPS;
-    const int nb_item = (int)lspans * 2 * BPS;    // ITEMS: bins per query slot in this item
+    const int nb_item = 2 * ((((int)lspans * BPS) + 3) & ~3);    // ITEMS: bins per query slot in this item (two half-runs)
 
     const float INF = __builtin_inff();
     float NEG_INF = -INF;
@@ -282,55 +282,50 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             if (tid + i * NT < ST * 32)
                 lds_b(buf)[tid + i * NT] = (stage_b[i] >= 0.9e38f) ? kPadBias : stage_b[i] * cs;
     };
-    // ITEMS with 64-row bins (BPS = 2 in the 8-tile spans of the IVF panel space; 4 while they were 16-tile spans): the bins of
-    // a span half are consecutive floats of the lane's slot, so they are collected in registers and stored as ONE vector per
-    // array instead of scattered 4-byte stores --
-    // in [item][slot][bin] order every lane writes its own line, and at one flush per 4 tiles those stores kept the
-    // CU's address path busy three quarters of the time (the list scan at nprobe 8 ran as long as at nprobe 32).
-    constexpr bool kVecBins = ITEMS && BPS == 2;          // (8-tile spans: 64-row bins come two per span half)
-    float2 pend1[2], pend2[2], pend3[2];
-    // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
-    auto flush_bin = [&](int64_t span, int bt) {
-        if (kVecBins) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                pend1[cb] = make_float2(pend1[cb].y, m1[cb]);
-                pend2[cb] = make_float2(pend2[cb].y, m2[cb]);
-                pend3[cb] = make_float2(pend3[cb].y, m3[cb]);
-                m1[cb] = INF;
-                m2[cb] = INF;
-                m3[cb] = INF;
-            }
-            if (bt == BPS - 1) {     // (the bins of a span half are always flushed in order 0..3 by the same wave)
-                const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    *reinterpret_cast<float2 *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
-                    *reinterpret_cast<float2 *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
-                    *reinterpret_cast<float2 *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
-                }
-            }
-            return;
-        }
-        // flat: [bin][query] (coalesced over the 32 queries of a lane half).  ITEMS: [item][slot][bin] so
-        // that the per-query select reads the bins of one probe as one contiguous run.
-        const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
-                                     (size_t)(((span - lspan0) * 2 + h) * BPS + bt)
-                               : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
-        const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
+    // ITEMS: the bins a lane produces for its query slot form ONE run per lane half -- [item][slot][half][span][bin of the
+    // half], nb_half floats per half (rounded up to 4) -- so they are collected in registers and leave as ONE 16-byte store
+    // per array every fourth bin, whatever the bin size.  (In [item][slot][bin] order every lane writes its own line: with a
+    // 4-byte store per bin and array those stores kept the CU's address path busy most of the time -- the list scan at
+    // nprobe 8 ran as long as at nprobe 32 -- and with [span][half][bin] order only the bins of one span half were adjacent.)
+    // Row parts start at multiples of 4 bins (the host sizes them so); the last vector of a part is filled with +inf, which
+    // lands on the padding behind the half's last bin.
+    float4 pend1[2], pend2[2], pend3[2];
+    const int nb_half = ITEMS ? (((int)lspans * BPS + 3) & ~3) : 0;
+    auto items_push = [&](int r) {      // bin r of this lane's half-run is complete (its minima are in m1 / m2 / m3)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            a.bin_m1[o + cb * cbs] = m1[cb];
-            a.bin_m2[o + cb * cbs] = m2[cb];
-            if (ITEMS) {
-                a.bin_m3[o + cb * cbs] = m3[cb];
-                m3[cb] = INF;
+            pend1[cb] = make_float4(pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]);
+            pend2[cb] = make_float4(pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]);
+            pend3[cb] = make_float4(pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]);
+            m1[cb] = INF;
+            m2[cb] = INF;
+            m3[cb] = INF;
+        }
+        if ((r & 3) == 3) {
+            const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(h * nb_half + r - 3);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                *reinterpret_cast<float4 *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                *reinterpret_cast<float4 *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                *reinterpret_cast<float4 *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
             }
-            if (!ITEMS) {
-                M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
-                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
-                M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
-            }
+        }
+    };
+    // a level-1 bin (BT tiles per lane half) is complete: write (min, second min), fold level 2
+    auto flush_bin = [&](int64_t span, int bt) {
+        if (ITEMS) {
+            items_push((int)(span - lspan0) * BPS + bt);
+            return;
+        }
+        // flat: [bin][query] (coalesced over the 32 queries of a lane half)
+        const size_t o = (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            a.bin_m1[o + cb * 32] = m1[cb];
+            a.bin_m2[o + cb * 32] = m2[cb];
+            M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
+            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+            M1[cb] = __builtin_fminf(M1[cb], m1[cb]);
             m1[cb] = INF;
             m2[cb] = INF;
         }
@@ -438,6 +433,8 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2), m3);  // drain the last tile
         flush_bin(span1 - 1, BPS - 1);
     }
+    if (ITEMS)       // fill the last vector of this part's run
+        for (int r = (int)(span1 - lspan0) * BPS; r & 3; ++r) items_push(r);
     if (ABL == 4 && a.dbg && lane == 0) {
         const unsigned long long t_end = stamp();
         unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NWAVES + wave) * 8;

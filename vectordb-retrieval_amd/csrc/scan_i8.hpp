@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
             for (int ks = 0; ks < KS; ++ks) bq[cb][ks] = a.qpanels[((size_t)(q0 / 32 + cb) * KS + ks) * 64 + lane];
     }
     const int nstages = (int)(span1 - span0) * SPS;
-    const int nb_item = (int)lspans * 2 * BPS;    // ITEMS: bins per query slot in this item
+    const int nb_item = 2 * ((((int)lspans * BPS) + 3) & ~3);    // ITEMS: bins per query slot in this item (two half-runs)
     const int INF = (int)kI8Inf;
     int m1[CB], m2[CB], m3[CB], M1[CB], M2[CB], Ms[CB];
 #pragma unroll
@@ -381,54 +381,49 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // ITEMS with 64-row bins (BPS = 2): the two bins of a span half leave as ONE 8-byte store per array (see scan_kernel)
-    constexpr bool kVecBins = ITEMS && BPS == 2;
-    typedef int int2v __attribute__((ext_vector_type(2)));
-    int2v pend1[CB], pend2[CB], pend3[CB];
-    // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]; ITEMS: [item][slot][bin]
-    auto flush_bin = [&](int64_t span, int bt) {
-        if (kVecBins) {
+    // ITEMS: the bins of a lane's query slot form one run per lane half, stored as ONE 16-byte vector per array every fourth
+    // bin (see scan_kernel: [item][slot][half][span][bin of the half], nb_half rounded up to 4)
+    int4v pend1[CB], pend2[CB], pend3[CB];
+    const int nb_half = ITEMS ? (((int)lspans * BPS + 3) & ~3) : 0;
+    auto items_push = [&](int r) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            pend1[cb] = int4v{pend1[cb].y, pend1[cb].z, pend1[cb].w, m1[cb]};
+            pend2[cb] = int4v{pend2[cb].y, pend2[cb].z, pend2[cb].w, m2[cb]};
+            pend3[cb] = int4v{pend3[cb].y, pend3[cb].z, pend3[cb].w, m3[cb]};
+            m1[cb] = INF;
+            m2[cb] = INF;
+            m3[cb] = INF;
+        }
+        if ((r & 3) == 3) {
+            const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(h * nb_half + r - 3);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                pend1[cb] = int2v{pend1[cb].y, m1[cb]};
-                pend2[cb] = int2v{pend2[cb].y, m2[cb]};
-                pend3[cb] = int2v{pend3[cb].y, m3[cb]};
-                m1[cb] = INF;
-                m2[cb] = INF;
-                m3[cb] = INF;
+                *reinterpret_cast<int4v *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
+                *reinterpret_cast<int4v *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
+                *reinterpret_cast<int4v *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
             }
-            if (bt == BPS - 1) {
-                const size_t o4 = bin_base * out_pitch + (size_t)out_col * nb_item + (size_t)(((span - lspan0) * 2 + h) * BPS);
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    *reinterpret_cast<int2v *>(a.bin_m1 + o4 + (size_t)cb * 32 * nb_item) = pend1[cb];
-                    *reinterpret_cast<int2v *>(a.bin_m2 + o4 + (size_t)cb * 32 * nb_item) = pend2[cb];
-                    *reinterpret_cast<int2v *>(a.bin_m3 + o4 + (size_t)cb * 32 * nb_item) = pend3[cb];
-                }
-            }
+        }
+    };
+    // a level-1 bin (BT tiles per lane half) is complete.  flat: [bin][query]
+    auto flush_bin = [&](int64_t span, int bt) {
+        if (ITEMS) {
+            items_push((int)(span - lspan0) * BPS + bt);
             return;
         }
-        const size_t o = ITEMS ? bin_base * out_pitch + (size_t)out_col * nb_item +
-                                     (size_t)(((span - lspan0) * 2 + h) * BPS + bt)
-                               : (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
-        const size_t cbs = ITEMS ? (size_t)32 * nb_item : 32;
+        const size_t o = (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
 #ifdef VDB_ABLATIONS
             if (!a.abl_no_bins)
 #endif
             {
-                a.bin_m1[o + cb * cbs] = __int_as_float(m1[cb]);
-                a.bin_m2[o + cb * cbs] = __int_as_float(m2[cb]);
+                a.bin_m1[o + cb * 32] = __int_as_float(m1[cb]);
+                a.bin_m2[o + cb * 32] = __int_as_float(m2[cb]);
             }
-            if (ITEMS) {
-                a.bin_m3[o + cb * cbs] = __int_as_float(m3[cb]);
-                m3[cb] = INF;
-            } else {
-                M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
-                if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
-                M1[cb] = imin(M1[cb], m1[cb]);
-            }
+            M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
+            if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
+            M1[cb] = imin(M1[cb], m1[cb]);
             m1[cb] = INF;
             m2[cb] = INF;
         }
@@ -571,6 +566,8 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
         select_phase_i8<CB, ITEMS, G>(acc, m1, m2, (unsigned)((BT - 1) * GPT), m3);
         flush_bin(span1 - 1, BPS - 1);
     }
+    if (ITEMS)       // fill the last vector of this part's run
+        for (int r = (int)(span1 - lspan0) * BPS; r & 3; ++r) items_push(r);
     if (DBG && a.dbg && lane == 0) {
         const unsigned long long t_end = stamp(), r_end = realtime_ticks();
         unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NWAVES + wave) * 8;
