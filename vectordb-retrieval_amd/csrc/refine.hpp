@@ -260,6 +260,81 @@ __global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
                     a.pids ? a.pids + o : nullptr);
 }
 
+// ---- flagged queries of the MFMA scan path: exhaustive exact scan, split on the device, merged by the last arriver -----
+// The select flags the (rare) query whose work lists overflowed; how many there are is known only on the device.  This
+// used to be two dispatches behind every search -- an exhaustive pass over S fixed splits and a merge of its partial lists,
+// both empty almost always.  Here ONE fixed grid reads the count (zero: every wave returns after one load), cuts every
+// flagged query into S = min(waves / count, max_split) row ranges, and the S partial lists of a query are merged by
+// whichever of its waves arrives last (agent-scope release / acquire around a per-query arrival counter, which the merging
+// wave resets: the counters are zero between searches).  S = 1 (many flagged queries): a wave writes its result directly.
+struct RefineFallbackArgs {
+    RefineCommon c;
+    const int32_t *fb_list;      // [count] flagged queries
+    const int32_t *fb_count;     // [1]
+    int max_split;
+    int64_t cap_units;           // capacity of the partial buffers in (query, split) units, >= the number of queries
+    double *pkeys;               // [cap_units][k]
+    int64_t *pids;
+    int32_t *done;               // [nq] arrival counters, zero on entry and on exit
+    float *D;                    // final rows, or (D == nullptr) per-shard partial rows
+    int64_t *I;
+    double *okeys;
+    int64_t *oids;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void refine_fallback_kernel(RefineFallbackArgs a) {
+    const int64_t count = *a.fb_count;
+    if (count <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    int64_t S = waves / count;
+    if (S > a.max_split) S = a.max_split;
+    if (S > a.cap_units / count) S = a.cap_units / count;
+    if (S < 1) S = 1;
+    const int64_t rows_per_split = ((a.c.N + S - 1) / S + 63) / 64 * 64;
+    for (int64_t u = wave0; u < count * S; u += waves) {
+        const int64_t f = u / S;
+        const int split = (int)(u - f * S);
+        const int64_t q = a.fb_list[f];
+        WaveTopK<KPL> tk;
+        tk.init(a.c.k);
+        scan_rows<KPL>(tk, a.c, a.c.Q + (size_t)q * a.c.D4, (int64_t)split * rows_per_split, (int64_t)(split + 1) * rows_per_split);
+        const size_t oq = (size_t)q * a.c.k;
+        if (S == 1) {
+            if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
+            else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
+            continue;
+        }
+        write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.pkeys + (size_t)u * a.c.k, a.pids + (size_t)u * a.c.k);
+        __threadfence();                                    // release: this lane's partial rows before the arrival below
+        int last = 0;
+        if (lane == 0) last = atomicAdd(&a.done[f], 1) == (int)S - 1;
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (!last) continue;
+        __threadfence();                                    // acquire: the other waves' partial rows
+        if (lane == 0) a.done[f] = 0;
+        tk.init(a.c.k);
+        const int total = (int)S * a.c.k;
+        const size_t o0 = (size_t)f * S * a.c.k;
+        for (int base = 0; base < total; base += 64) {
+            const int i = base + lane;
+            bool valid = i < total;
+            uint64_t key = ~0ull;
+            int64_t id = -1;
+            if (valid) {
+                id = __builtin_nontemporal_load(a.pids + o0 + i);
+                key = sortable_u64(__builtin_nontemporal_load(a.pkeys + o0 + i));
+                valid = id >= 0;
+            }
+            tk.offer(key, id, valid);
+        }
+        if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
+        else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
+    }
+}
+
 // ---- rerank mode: explicit candidate ids per query ---------------------------------------------------
 struct RerankArgs {
     RefineCommon c;

@@ -80,13 +80,13 @@ inline QueryBatchInfo *batch_info(Workspace &ws);
 
 struct Workspace {
     DevBuf qpad, qpanels, qpanels8, qrows8, info, eps, bin_m1, bin_m2, bin_m3, bin_m4, bin_m5, sb_m1, sb_m2, sb_span;
-    DevBuf cand, rescan, counts, fallback, fb_list, small;  // small: fb_count (int) + 2 stat counters
+    DevBuf cand, rescan, counts, fallback, fb_list, fb_done /* arrival counters of refine_fallback_kernel */, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
     size_t bytes() const {
         const DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &bin_m4, &bin_m5, &sb_m1, &sb_m2, &sb_span, &cand,
-                               &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d,
+                               &rescan, &counts, &fallback, &fb_list, &fb_done, &small, &pkeys, &pids, &stage_q, &stage_d,
                                &stage_i, &dense};
         size_t s = 0;
         for (auto b : all) s += b->cap;
@@ -94,7 +94,7 @@ struct Workspace {
     }
     void release() {
         DevBuf *all[] = {&qpad, &qpanels, &qpanels8, &qrows8, &info, &eps, &bin_m1, &bin_m2, &bin_m3, &bin_m4, &bin_m5, &sb_m1, &sb_m2, &sb_span, &cand,
-                         &rescan, &counts, &fallback, &fb_list, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
+                         &rescan, &counts, &fallback, &fb_list, &fb_done, &small, &pkeys, &pids, &stage_q, &stage_d, &stage_i,
                          &dense};
         for (auto b : all) b->release();
     }
