@@ -185,12 +185,16 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       any vdb_set_option / add / train drops the graph; the caller keeps the buffers alive and
  *                       rewrites the queries in place
  *   tuning knobs (scripts/sweep_*.py)
- *     "i8_variant"      0..5: tile / stage / wave shapes of the flat int8 scan
+ *     "i8_variant"      0..7: tile / stage / wave shapes of the flat int8 scan (6 / 7: variant 3 with a pacing barrier
+ *                       per 1 / 2 tiles)
  *     "i8_group"        8 (default) | 4 rows per select group of the flat int8 scan
+ *     "i8_ring"         0 auto (4) | 2 | 4 | 8 LDS staging stages of the serving-shaped and IVF int8 scans
  *     "ivf_nw"          0 auto | 2 / 4 / 8 waves per IVF work item
- *     "ivf_bt"          0 auto | 4 / 16 tiles per IVF bin
- *     "ivf_part"        0 auto | spans (512 rows) per row part of the IVF list scan: long lists are cut into parts
- *                       scanned by one workgroup each
+ *     "ivf_bt"          0 auto | 4 (64-row bins) | 16 (the largest: one bin per half of a 256-row span)
+ *     "ivf_tps"         D > 128, takes effect at the next vdb_ivf_add: 0 auto | 16 (256-row spans, 64-row bins) | 64
+ *                       (1024-row spans, 256-row bins) of the p16 panel space
+ *     "ivf_part"        0 auto | spans (256 rows) per row part of the IVF list scan: long lists are cut into parts
+ *                       scanned by one workgroup each (rounded up to a multiple of 4 bins)
  *     "select_variant"  0..2;  "spans_per_chunk", "kloop_qgroup": grid shaping of the flat scans
  *     "scan_variant"    and the timing-only ablations exist only in -DVDB_ABLATIONS builds (`make ablations`, WRONG
  *                       results by design); the shipped library rejects them. */
