@@ -173,6 +173,10 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       takes effect at the next vdb_add
  *     "panel_dtype"     0 auto: byte-valued integer corpora are ALSO kept as an int8 scan copy, and integer query batches
  *                       in the byte window are scanned with int8 MFMA | 1 fp16 scan only
+ *     "stream_panels"   D > 128, takes effect at the next vdb_add: 0 (default) the fp16 scan copy stays resident next to the
+ *                       float32 rows | 1 it is NOT kept: every search converts the float32 rows slab by slab into one
+ *                       scratch slab and scans that (same results; 1.8x -> ~1.15x the corpus bytes resident for a corpus that
+ *                       is not exact in fp16, one extra pass over the rows per query batch)
  *     "upload_block_mb" staging block of the row-block ingestion (default 64)
  *     "small_batch"     1 (default): batches of <= 512 queries are scanned with finer row chunks and, up to 256 queries,
  *                       1 / 2 / 4-wave workgroups, so that the grid still covers the chip; D > 128: waves without queries

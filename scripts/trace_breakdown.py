@@ -1,34 +1,23 @@
 #!/usr/bin/env python3
-"""Per-search kernel breakdown from a rocprofv3 --kernel-trace CSV of an IVF bench run: average device time of every
-kernel over the last 8 searches (from the coarse stage's query_stats_kernel -- one per search: the list stage reuses its statistics -- to the fallback ivf_scan_kernel), the
-span of a search and the sum of its kernel times (the difference is launch gaps).
-Usage: python scripts/trace_breakdown.py <..._kernel_trace.csv>"""
+"""Per-search kernel breakdown from a rocprofv3 --kernel-trace CSV of a bench run (flat or IVF).
+
+A device-resident search starts with its one memset (__amd_rocclr_fillBufferAligned) and its dispatches follow back to
+back, so the trace is cut at every memset; the dispatch sequence that occurs most often is the timed loop's search, and
+the average device time of each of its kernels, the span of a search and the sum of its kernel times (the difference is
+launch gaps) are printed.  Usage: python scripts/trace_breakdown.py <..._kernel_trace.csv>"""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "ivf_select_kernel" in n]
-sel = idx[-8:]
-agg, spans = collections.OrderedDict(), []
-for s in sel:
-    i, cnt = s, 0
-    while i > 0:
-        if "query_stats_kernel" in names[i]:
-            cnt += 1
-            if cnt == 1:
-                break
-        i -= 1
-    j = s
-    while j < len(names) - 1 and "ivf_scan_kernel" not in names[j]:
-        j += 1
-    busy = 0
-    for r in rows[i:j + 1]:
-        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        busy += d
-        k = r["Kernel_Name"][:90]
-        agg[k] = agg.get(k, 0) + d
-    spans.append((int(rows[j]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"]), busy, j - i + 1))
-for k, v in agg.items():
-    print(f"{v / len(sel) / 1e3:8.1f} us  {k}")
-print(f"search span {sum(s[0] for s in spans) / len(spans) / 1e3:.1f} us, kernels busy {sum(s[1] for s in spans) / len(spans) / 1e3:.1f} us, "
-      f"{sum(s[2] for s in spans) / len(spans):.0f} dispatches")
+cuts = [i for i, r in enumerate(rows) if "fillBufferAligned" in r["Kernel_Name"]]
+cycles = [rows[a:b] for a, b in zip(cuts, cuts[1:])]
+sig = collections.Counter(tuple(r["Kernel_Name"] for r in c) for c in cycles)
+if not sig:
+    sys.exit("no searches found")
+best, count = sig.most_common(1)[0]
+sel = [c for c in cycles if tuple(r["Kernel_Name"] for r in c) == best]
+n = len(sel)
+dur = [sum(int(c[j]["End_Timestamp"]) - int(c[j]["Start_Timestamp"]) for c in sel) / n / 1e3 for j in range(len(best))]
+for name, d in zip(best, dur):
+    print(f"{d:8.1f} us  {name[:110]}")
+span = sum(int(c[-1]["End_Timestamp"]) - int(c[0]["Start_Timestamp"]) for c in sel) / n / 1e3
+print(f"search span {span:.1f} us, kernels busy {sum(dur):.1f} us, {len(best)} dispatches (mean of {n} searches with this dispatch sequence)")

@@ -93,7 +93,25 @@ def _ivf_cases():
     return out
 
 
-@pytest.mark.parametrize("i,n,d,nlist,nprobe,nq,k,metric,kind", _ivf_cases())
+def _ivf_cases_wide():
+    """Round 3: the list-major scans that are new or re-laid -- D > 128 (items-mode K-loop scan, both span sizes), and
+    byte-valued corpora with D <= 128 (int8 items-mode scan: 256-row spans, run-ordered vector bin stores, staging ring)."""
+    import os
+    rng = np.random.default_rng(303)
+    out = []
+    for i in range(int(os.environ.get("VDBHIP_FUZZ_IVF_WIDE_CASES", "12"))):
+        wide = i % 2 == 0
+        n = int(rng.integers(15000, 60000))
+        d = int(rng.integers(129, 800)) if wide else int(rng.integers(8, 129))
+        nlist = int(rng.integers(4, 80))
+        nq = int(rng.integers(1, 700))
+        k = int(rng.choice([1, 5, 10, 20, 50]))
+        kind = str(rng.choice(["gauss", "ints", "heavy", "offset"] if wide else ["bytes", "sbytes", "ints"]))
+        out.append((100 + i, n, d, nlist, int(rng.integers(1, nlist + 1)), nq, k, str(rng.choice(["l2", "ip"])), kind))
+    return out
+
+
+@pytest.mark.parametrize("i,n,d,nlist,nprobe,nq,k,metric,kind", _ivf_cases() + _ivf_cases_wide())
 def test_random_ivf_configurations_bit_exact(oracle, i, n, d, nlist, nprobe, nq, k, metric, kind):
     """IVF-Flat with injected centroids == brute force restricted to the probed lists (oracle/ivf_oracle.c), for random
     list counts (including empty and tiny lists), probe counts, dims on both sides of the MFMA list-scan limits."""
@@ -107,6 +125,8 @@ def test_random_ivf_configurations_bit_exact(oracle, i, n, d, nlist, nprobe, nq,
         C[0] = 1e4            # a centroid far from everything: an empty list
     idx = vdbhip.IVFFlatIndex(d, nlist, metric, 0)
     idx.set_centroids(C)
+    if d > 128 and i % 3 == 0:
+        idx.set_option("ivf_tps", 64)       # 1024-row spans / 256-row bins instead of the automatic choice
     idx.add(X, id_base=3)
     lor = idx.assignment()
     np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, metric))

@@ -99,16 +99,18 @@ __global__ __launch_bounds__(256) void build_panels_kernel(const float *__restri
 // Row mapping: span = 1024 rows = 64 tiles; tile t of span s, MFMA row rho = 4g+i  <->  corpus row
 // 1024 s + 256 g + 4 t + i, so the lane group g = l>>4 of the C/D layout (col = l&15, rows 4g..4g+3) walks 256
 // CONSECUTIVE corpus rows per span, one quad per tile.
+// tile0 / panels: tiles [tile0, tile0 + ntiles) are written to panels[0 ...) -- the whole corpus at build time (tile0 = 0), or
+// one slab of a streamed scan (option "stream_panels").  panels == nullptr: only the fp16-exactness flag is taken.
 __global__ __launch_bounds__(256) void build_panels16_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
                                                              int ks32, int64_t ntiles, float sx,
-                                                             half8 *__restrict__ panels, IndexStats *st) {
+                                                             half8 *__restrict__ panels, IndexStats *st, int64_t tile0 = 0) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
     const int ks = (int)(tk % ks32);
-    const int64_t tile = tk / ks32;
+    const int64_t tile = tile0 + tk / ks32;
     int inexact = 0;
-    if (tile < ntiles) {
+    if (tk / ks32 < ntiles) {
         const int rho = lane & 15, kq = lane >> 4;
         const int g = rho >> 2, i = rho & 3;
         const int64_t span = tile / kTilesPerSpan16;
@@ -125,9 +127,9 @@ __global__ __launch_bounds__(256) void build_panels16_kernel(const float *__rest
             inexact |= ((float)hv != v);
             out[j] = hv;
         }
-        panels[gid] = out;
+        if (panels) panels[gid] = out;
     }
-    if (__any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
+    if (st && __any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
 // bias (C-init of the MFMA accumulators): ||x||^2 for L2, 0 for IP, pad marker beyond N.

@@ -37,6 +37,8 @@ struct ScanArgs {
     int spans_per_chunk;   // base chunk length; the first `chunk_rem` chunks are one span longer
     int chunk_rem;
     int nchunks;
+    int chunk0;            // scan16_kloop_kernel, streamed panels: this launch covers chunks [chunk0, chunk0 + nchunks) and
+                           // `panels` is rebased so that the absolute tile numbers of those chunks land in the slab
     int nqtiles;           // query tiles (64 * NWAVES queries each)
     int64_t Qpad;          // multiple of 512
     int64_t nq_valid;      // flat mode: queries >= nq_valid are padding (0 = unknown: treat every column as real)

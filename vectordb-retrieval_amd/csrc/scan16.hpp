@@ -237,8 +237,8 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
     const int per_group = cpx * ex.qgroup;
     const int qg = j / per_group, rem = j - qg * per_group;
     const int ci = rem / ex.qgroup, qt = qg * ex.qgroup + (rem - ci * ex.qgroup);
-    const int chunk = x + 8 * ci;
-    if (chunk >= a.nchunks || qt >= a.nqtiles) return;
+    if (x + 8 * ci >= a.nchunks || qt >= a.nqtiles) return;
+    const int chunk = a.chunk0 + x + 8 * ci;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;                                // lane group = bin of the span

@@ -159,6 +159,12 @@ struct vdb_index_s {
                                              // the parent's ivf_zero buffer) -- the next search_device_impl skips its own memset
     int64_t info_valid_nq = -1;              // queries whose statistics the last search_batch left in batch_info(ws) (-1: none)
     bool tile16 = false;                     // panels in the p16 layout (16-row tiles, 1024-row spans, 4 bins per span)
+    // option "stream_panels" (D > 128, takes effect at the next add): the fp16 panels are NOT kept -- every search converts
+    // the float32 rows slab by slab into one scratch slab and scans it (search_flat.inc).  Halves the footprint of a
+    // non-fp16-exact corpus (the float32 rows must stay for the exact refine) at the price of one conversion pass per batch.
+    int stream_panels_opt = 0;
+    bool panels_streamed = false;
+    DevBuf slab;
     bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
                                              // not their order or distances (dense.hpp, DenseSelectArgs.set_only)
     // per-search
@@ -401,10 +407,12 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     if (dims_ok && !h->nonfinite) {
         const int64_t ntiles = h->Npad / (h->tile16 ? kTileRows16 : kTileRows);
         const int ksl = h->tile16 ? h->ksteps / 2 : h->ksteps;          // k-steps of the layout (32 or 16 dims)
-        h->panels.reserve((size_t)ntiles * ksl * 64 * sizeof(half8));
+        h->panels_streamed = h->tile16 && h->stream_panels_opt != 0;
+        if (h->panels_streamed) h->panels.release();
+        else h->panels.reserve((size_t)ntiles * ksl * 64 * sizeof(half8));
         const int64_t threads = ntiles * ksl * 64;
-        if (h->tile16)
-            build_panels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, ksl, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
+        if (h->tile16)    // (streamed: the pass only takes the fp16-exactness flag)
+            build_panels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, ksl, ntiles, h->sx, h->panels_streamed ? nullptr : h->panels.as<half8>(), h->stats.as<IndexStats>());
         else
             build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
         VDB_HIP(hipGetLastError());
@@ -509,7 +517,7 @@ int vdb_destroy(vdb_handle h) {
         if (!h) return;
         set_device(h->device);
         (void)hipDeviceSynchronize();
-        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
+        DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->slab, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
                          &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid,
                          &h->ivf_zero, &h->ivf_slot_off, &h->ivf_list_item0, &h->ivf_item_list,
                          &h->ivf_item_slot0, &h->ivf_item_bin0, &h->ivf_plan, &h->ivf_slot_of};
@@ -720,7 +728,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.dim = h->dim;
         s.metric = h->metric;
         s.corpus_fp16_exact = h->corpus_fp16_exact ? 1 : 0;
-        s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->bias.cap + h->stats.cap +
+        s.bytes_resident = (int64_t)(h->x32.cap + h->xnorm2.cap + h->panels.cap + h->slab.cap + h->bias.cap + h->stats.cap +
                                      h->panels8.cap + h->bias8.cap + h->rows8.cap + h->rowstat8.cap + h->ws.bytes());
         {   // IVF: the CSR arrays, the per-batch plan buffers and the coarse quantizer's own index and workspace
             const DevBuf *ivf[] = {&h->ivf_offsets, &h->ivf_ids, &h->ivf_probe_d, &h->ivf_probe_i, &h->ivf_list_pspan0,
@@ -824,6 +832,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "panel_layout") {   // 0 auto, 1 = 32-row tiles for every D, 2 = p16 for every D (next add)
             if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "panel_layout must be 0, 1 or 2");
             h->layout_override = (int)value;
+        } else if (k == "stream_panels") {  // D > 128, next add: 0 keep the fp16 panels resident | 1 convert them per search
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "stream_panels must be 0 or 1");
+            h->stream_panels_opt = (int)value;
         } else if (k == "panel_dtype") {    // 0 auto (int8 scan copy used when corpus and queries allow), 1 = fp16 scan only
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_dtype must be 0 or 1");
             h->i8_disable = (int)value;
