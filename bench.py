@@ -643,6 +643,9 @@ def main() -> int:
     ap.add_argument("--nprobe", type=int, default=0, help="IVF workloads: lists probed per query (0 = the config's set)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="N > 1: weak = every rank holds the workload's rows; strong = the rows are split over the ranks")
+    ap.add_argument("--stream-panels", action="store_true",
+                    help="device-generated D > 128 workloads: option stream_panels = 1 (the fp16 scan copy is converted per "
+                         "search instead of kept resident: smaller footprint, one extra pass over the rows per batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only: no also.* legs")
     args = ap.parse_args()
@@ -784,6 +787,8 @@ def device_corpus_line(args, workload, vdbhip, torch, dev, local_rank, stream):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     index = vdbhip.FlatIndex(d, metric, local_rank)
+    if args.stream_panels:
+        index.set_option("stream_panels", 1)
     index.add_device(X_t.data_ptr(), n, id_base=0)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
@@ -799,7 +804,7 @@ def device_corpus_line(args, workload, vdbhip, torch, dev, local_rank, stream):
            "roofline": roofline_of(st, nq, n, d, workload),
            "pipeline": pipeline_of(st, nq, build_s, float(n) * d * 4),
            "recall@10_vs_float64_torch_sample": round(device_check(X_t, q_t, I_t, k, metric, 0), 6),
-           "result_checksum": result_checksum(I_t)}
+           "result_checksum": result_checksum(I_t), "stream_panels": bool(args.stream_panels)}
     index.close()
     return out
 
@@ -830,6 +835,8 @@ def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, st
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     index = vdbhip.FlatIndex(d, metric, local_rank)
+    if args.stream_panels:
+        index.set_option("stream_panels", 1)
     if X is None:
         index.add_device(X_t.data_ptr(), n, id_base=lo)
     else:

@@ -177,6 +177,8 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       float32 rows | 1 it is NOT kept: every search converts the float32 rows slab by slab into one
  *                       scratch slab and scans that (same results; 1.8x -> ~1.15x the corpus bytes resident for a corpus that
  *                       is not exact in fp16, one extra pass over the rows per query batch)
+ *     "stream_slab_rows" rows of that scratch slab (0 = default 1 280 000, rounded down to whole scan chunks whose
+ *                       workgroups fill whole rounds of the chip)
  *     "upload_block_mb" staging block of the row-block ingestion (default 64)
  *     "small_batch"     1 (default): batches of <= 512 queries are scanned with finer row chunks and, up to 256 queries,
  *                       1 / 2 / 4-wave workgroups, so that the grid still covers the chip; D > 128: waves without queries

@@ -132,6 +132,42 @@ __global__ __launch_bounds__(256) void build_panels16_kernel(const float *__rest
     if (st && __any(inexact) && (threadIdx.x & 63) == 0) atomic_set_flag(&st->not_fp16_exact);
 }
 
+// Slab conversion of a streamed scan (option "stream_panels"): the same p16 panels as build_panels16_kernel for tiles
+// [tile0, tile0 + ntiles), written to panels[0 ...).  One WAVE per tile walking all its k-steps (the build kernel's one
+// thread per 16 bytes of output means 4.7 M workgroups for a 12.5M x 768 shard: dispatch-bound at ~1 TB/s, 60 ms per pass --
+// longer than a third of the scan it feeds): per k-step a wave reads 16 rows x 128 contiguous bytes as two 16-byte loads per
+// lane and writes 1 KiB.
+__global__ __launch_bounds__(256) void convert_slab16_kernel(const float *__restrict__ X, int64_t N, int D, int D4, int ks32,
+                                                             int64_t tile0, int64_t ntiles, float sx,
+                                                             half8 *__restrict__ panels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tl >= ntiles) return;
+    const int64_t tile = tile0 + tl;
+    const int rho = lane & 15, kq = lane >> 4;
+    const int g = rho >> 2, i = rho & 3;
+    const int64_t span = tile / kTilesPerSpan16;
+    const int t = (int)(tile - span * kTilesPerSpan16);
+    const int64_t row = span * kSpanRows16 + (int64_t)g * kBinRows + 4 * t + i;
+    const bool live = row < N;
+    const float *xr = X + (size_t)(live ? row : 0) * D4;
+    half8 *out = panels + (size_t)tl * ks32 * 64 + lane;
+#pragma unroll 4
+    for (int ks = 0; ks < ks32; ++ks) {
+        const int d0 = ks * 32 + kq * 8;
+        half8 o;
+        if (live && d0 + 8 <= D4) {          // (D4 is D padded to a multiple of 4 with zeros: whole float4s)
+            const float4 a = *reinterpret_cast<const float4 *>(xr + d0), b = *reinterpret_cast<const float4 *>(xr + d0 + 4);
+            o[0] = (_Float16)(a.x * sx); o[1] = (_Float16)(a.y * sx); o[2] = (_Float16)(a.z * sx); o[3] = (_Float16)(a.w * sx);
+            o[4] = (_Float16)(b.x * sx); o[5] = (_Float16)(b.y * sx); o[6] = (_Float16)(b.z * sx); o[7] = (_Float16)(b.w * sx);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((live && d0 + j < D) ? xr[d0 + j] * sx : 0.f);
+        }
+        out[(size_t)ks * 64] = o;
+    }
+}
+
 // bias (C-init of the MFMA accumulators): ||x||^2 for L2, 0 for IP, pad marker beyond N.
 __global__ __launch_bounds__(256) void build_bias_kernel(const float *__restrict__ xnorm2, int64_t N, int64_t Npad,
                                                          int metric, float *__restrict__ bias) {

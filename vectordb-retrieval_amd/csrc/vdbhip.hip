@@ -49,7 +49,7 @@ struct DevBuf {
         if (p) VDB_HIP(hipFree(p));
         p = nullptr;
         cap = 0;
-        const size_t want = bytes + (bytes >> 3);
+        const size_t want = bytes + std::min<size_t>(bytes >> 3, (size_t)256 << 20);   // (growth slack: 1/8, at most 256 MiB)
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) throw Error(VDB_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
         cap = want;
@@ -163,8 +163,9 @@ struct vdb_index_s {
     // the float32 rows slab by slab into one scratch slab and scans it (search_flat.inc).  Halves the footprint of a
     // non-fp16-exact corpus (the float32 rows must stay for the exact refine) at the price of one conversion pass per batch.
     int stream_panels_opt = 0;
+    int64_t stream_slab_rows = 0;            // option "stream_slab_rows" (0 = default)
     bool panels_streamed = false;
-    DevBuf slab;
+    DevBuf slab;                             // the scratch slab of a streamed index
     bool set_only = false;                   // coarse quantizer of an IVF index: callers use the SET of the k nearest rows,
                                              // not their order or distances (dense.hpp, DenseSelectArgs.set_only)
     // per-search
@@ -835,6 +836,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "stream_panels") {  // D > 128, next add: 0 keep the fp16 panels resident | 1 convert them per search
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "stream_panels must be 0 or 1");
             h->stream_panels_opt = (int)value;
+        } else if (k == "stream_slab_rows") {  // rows of the scratch slab of a streamed index (0 = default 1 280 000)
+            if (value < 0) throw Error(VDB_ERR_INVALID, "stream_slab_rows must be >= 0");
+            h->stream_slab_rows = value;
         } else if (k == "panel_dtype") {    // 0 auto (int8 scan copy used when corpus and queries allow), 1 = fp16 scan only
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "panel_dtype must be 0 or 1");
             h->i8_disable = (int)value;
