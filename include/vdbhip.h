@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VDB_ABI_VERSION 2
+#define VDB_ABI_VERSION 3
 
 typedef struct vdb_index_s *vdb_handle;
 
@@ -90,13 +90,20 @@ int vdb_create(int dim, int metric, int device, vdb_handle *out);
 int vdb_destroy(vdb_handle h);
 
 /* replaces index.add(vectors) (exact_search.py:39; modular.py:124-130 keeps the raw matrix):
- * uploads n rows (row-major float32, host memory) and builds the scan copy.  Row i gets id
- * id_base + i (row-sharded corpora pass their shard offset).  One-shot: a second call replaces the corpus.
+ * uploads n rows (row-major float32, host memory) and builds the scan copy.  APPENDS, as faiss.Index.add does: row i of
+ * the index (in insertion order over all adds) gets id id_base + i; id_base (row-sharded corpora pass their shard offset)
+ * belongs to the index -- every add of one index passes the same value (VDB_ERR_INVALID otherwise), vdb_reset empties the
+ * index.  An append re-derives the scan copies from the float32 rows on the device (~0.3 s per 12.5M x 768 rows) and
+ * needs room for the old and the grown row buffer side by side while it copies.
  * The rows are streamed in blocks (option "upload_block_mb", default 64 MiB) through two pinned staging buffers, so
  * x_host may be a memory-mapped file far larger than host RAM comfortably holds (dataset.py:376-471, 1001-1052). */
 int vdb_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
 /* same, rows already in device memory of the handle's GPU */
 int vdb_add_device(vdb_handle h, const float *x_dev, int64_t n, int64_t id_base, void *stream);
+
+/* replaces index.reset(): drops every row (flat and IVF; an IVF index keeps its centroids).  A search before the next add
+ * fails with VDB_ERR_STATE. */
+int vdb_reset(vdb_handle h);
 
 /* replaces index.search(queries, k) (exact_search.py:58,78): host buffers, synchronous.
  * D (nq,k) float32, I (nq,k) int64, caller-allocated. */
@@ -138,7 +145,8 @@ int vdb_ivf_train(vdb_handle h, int nlist, const float *x_host, int64_t n, int n
 /* inject centroids (nlist, dim) instead of training -- used by parity tests and index loading */
 int vdb_ivf_set_centroids(vdb_handle h, const float *centroids_host, int nlist);
 int vdb_ivf_get_centroids(vdb_handle h, float *centroids_host);
-/* assign rows to their nearest centroid and build the inverted lists (CSR, vectors grouped by list) */
+/* assign rows to their nearest centroid and build the inverted lists (CSR, vectors grouped by list).  APPENDS like vdb_add
+ * (same id rule); the lists are the ones a single add of all rows builds (rows of a list stay in insertion order). */
 int vdb_ivf_add(vdb_handle h, const float *x_host, int64_t n, int64_t id_base);
 /* same with the list of every row given (int32 (n), as vdb_ivf_get_assignment returned it for this corpus and these
  * centroids): what loading a persisted index does -- no coarse assignment pass (covertree_v2_2.py:184-282 is the

@@ -461,3 +461,67 @@ def test_msmarco_shaped_ivf_through_the_plugins(vdb, oracle):
     assert r10 > 0.85
     d1, i1 = algo.search(Q[0], k=20)
     np.testing.assert_array_equal(i1, io[0])
+
+
+@pytest.mark.parametrize("d,metric,kind", [(64, "l2", "gauss"), (128, "l2", "bytes"), (200, "ip", "gauss")])
+def test_add_appends_to_the_lists_like_faiss(vdb, oracle, d, metric, kind):
+    """`faiss.IndexIVF.add` appends (a second vdb_add used to replace the corpus silently).  Three adds build
+    the index one add of the concatenated rows builds: same assignment, ids and results, bit for bit; the id base belongs
+    to the index; `reset` drops the rows and keeps the centroids; new centroids drop the rows."""
+    n, nlist, nq, k = 30000, 64, 150, 10
+    rng = np.random.default_rng(d)
+    if kind == "bytes":
+        X = rng.integers(0, 256, (n, d)).astype(np.float32)
+        Q = rng.integers(0, 256, (nq, d)).astype(np.float32)
+    else:
+        X, Q = _data(n, d, nq, seed=d)
+    C = X[rng.choice(n, nlist, replace=False)].copy()
+    whole = vdb.IVFFlatIndex(d, nlist, metric, 0)
+    whole.set_centroids(C)
+    whole.add(X, id_base=500)
+    parts = vdb.IVFFlatIndex(d, nlist, metric, 0)
+    parts.set_centroids(C)
+    cuts = [0, 9000, 9001, 22000, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        parts.add(X[a:b], id_base=500)
+        assert parts.ntotal == b
+    parts.add(X[:0], id_base=500)                       # (an empty append changes nothing)
+    np.testing.assert_array_equal(parts.assignment(), whole.assignment())
+    for nprobe in (1, 8, nlist):
+        whole.set_nprobe(nprobe)
+        parts.set_nprobe(nprobe)
+        Dw, Iw = whole.search(Q, k)
+        Dp, Ip = parts.search(Q, k)
+        np.testing.assert_array_equal(Ip, Iw)
+        np.testing.assert_array_equal(Dp, Dw)
+    Do, Io = oracle.ivf_search(X, C, whole.assignment(), Q, k, nlist, metric, id_base=500)
+    np.testing.assert_array_equal(Ip, Io)
+    np.testing.assert_array_equal(Dp, Do)
+    with pytest.raises(ValueError, match="id base"):
+        parts.add(X[:10], id_base=0)
+    # stored assignment, appended
+    given = vdb.IVFFlatIndex(d, nlist, metric, 0)
+    given.set_centroids(C)
+    lor = whole.assignment()
+    given.add(X[:12345], id_base=500, list_of_row=lor[:12345])
+    given.add(X[12345:], id_base=500, list_of_row=lor[12345:])
+    given.set_nprobe(8)
+    whole.set_nprobe(8)
+    np.testing.assert_array_equal(given.search(Q, k)[1], whole.search(Q, k)[1])
+    # reset: rows gone, centroids kept, another id base is fine
+    parts.reset()
+    assert parts.ntotal == 0
+    with pytest.raises(RuntimeError):
+        parts.search(Q, k)
+    parts.add(X[:5000], id_base=7)
+    parts.set_nprobe(nlist)
+    Db, Ib = oracle.knn(X[:5000], Q, k, metric, id_base=7)
+    Dr, Ir = parts.search(Q, k)
+    np.testing.assert_array_equal(Ir, Ib)
+    np.testing.assert_array_equal(Dr, Db)
+    parts.set_centroids(C[::-1].copy())                 # new centroids: the next add starts over
+    assert parts.ntotal == 0
+    parts.add(X[:4000], id_base=0)
+    assert parts.stats()["ntotal"] == 4000
+    for i in (whole, parts, given):
+        i.close()

@@ -755,3 +755,69 @@ def test_streamed_panels_halve_the_footprint_and_stay_exact(vdb, oracle, d, metr
         assert streamed < resident - 0.4 * panels, (streamed, resident, panels)
     print(f"resident {resident / 2**20:.0f} MiB -> streamed {streamed / 2**20:.0f} MiB (corpus {X.nbytes / 2**20:.0f} MiB)")
     idx.close()
+    if n < 100_000:            # the same through the plugin's config entry (`engine_options`), and a bad name fails loudly
+        algo = vdb.HipExactSearch("exact_streamed", d, metric=metric, engine_options={"stream_panels": 1})
+        algo.build_index(X)
+        Dp, Ip = algo.batch_search(Q, 10)
+        np.testing.assert_array_equal(Ip, Io)
+        np.testing.assert_array_equal(Dp, Do)
+        with pytest.raises(Exception):
+            vdb.HipExactSearch("bad", d, metric=metric, engine_options={"no_such_option": 1}).build_index(X)
+
+
+@pytest.mark.parametrize("d,metric,kind", [(128, "l2", "bytes"), (64, "l2", "gauss"), (96, "ip", "gauss"), (200, "l2", "gauss"),
+                                           (384, "ip", "streamed")])
+def test_add_appends_like_faiss(vdb, oracle, d, metric, kind):
+    """`faiss.Index.add` appends; `vdb_add` used to replace the corpus on a second call.  Adds of
+    uneven parts (host and device memory) give the index of the concatenated rows: ids continue, results bit-equal to the
+    oracle on the whole corpus; the id base belongs to the index; `reset` empties it."""
+    import torch
+
+    n, nq, k = 70000, 130, 10
+    rng = np.random.default_rng(d)
+    if kind == "bytes":
+        X = rng.integers(0, 256, (n, d)).astype(np.float32)
+        Q = rng.integers(0, 256, (nq, d)).astype(np.float32)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Do, Io = oracle.knn(X, Q, k, metric, id_base=300)
+    idx = vdb.FlatIndex(d, metric, 0)
+    if kind == "streamed":
+        idx.set_option("stream_panels", 1)
+    cuts = [0, 1, 20000, 20007, 52000, n]
+    for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if j == 3:                                      # one part from device memory
+            part = torch.from_numpy(X[a:b]).cuda()
+            idx.add_device(part.data_ptr(), b - a, id_base=300)
+            torch.cuda.synchronize()
+        else:
+            idx.add(X[a:b], id_base=300)
+        assert idx.ntotal == b and idx.stats()["ntotal"] == b
+        if j == 2:                                      # searches between appends see the rows so far
+            D, I = idx.search(Q, k)
+            Dp, Ip = oracle.knn(X[:b], Q, k, metric, id_base=300)
+            np.testing.assert_array_equal(I, Ip)
+            np.testing.assert_array_equal(D, Dp)
+    idx.add(X[:0], id_base=300)
+    D, I = idx.search(Q, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    st = idx.stats()
+    assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, st
+    if kind == "bytes":
+        assert st["has_i8_copy"] == 1 and st["scan_dtype"] == 1
+    with pytest.raises(ValueError, match="id base"):
+        idx.add(X[:10], id_base=0)
+    D2, I2 = idx.search(Q, k)                           # (the refused add left the index as it was)
+    np.testing.assert_array_equal(I2, Io)
+    idx.reset()
+    assert idx.ntotal == 0
+    with pytest.raises(RuntimeError, match="not been built"):
+        idx.search(Q, k)
+    idx.add(X[:3000], id_base=9)
+    D3, I3 = idx.search(Q, k)
+    Ds, Is = oracle.knn(X[:3000], Q, k, metric, id_base=9)
+    np.testing.assert_array_equal(I3, Is)
+    np.testing.assert_array_equal(D3, Ds)
+    idx.close()

@@ -132,9 +132,10 @@ __global__ __launch_bounds__(256) void ivf_fallback_kernel(IvfFallbackArgs a) {
     }
 }
 
-// ---- CSR build: xperm[i] = x[perm[i]], ids[i] = id_base + perm[i] ------------------------------------
+// ---- CSR build: xperm[i] = x[perm[i]], ids[i] = id_base + perm[i] (src_ids: ids[i] = src_ids[perm[i]], the append) ---
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ perm,
-                                                          int64_t n, int D4, int64_t id_base, float *__restrict__ xperm,
+                                                          int64_t n, int D4, int64_t id_base,
+                                                          const int64_t *__restrict__ src_ids, float *__restrict__ xperm,
                                                           int64_t *__restrict__ ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = n * (D4 / 4);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     const int c = (int)(i - r * (D4 / 4));
     const int64_t src = perm[r];
     reinterpret_cast<float4 *>(xperm)[i] = reinterpret_cast<const float4 *>(x)[src * (D4 / 4) + c];
-    if (c == 0) ids[r] = id_base + src;
+    if (c == 0) ids[r] = src_ids ? src_ids[src] : id_base + src;
 }
 
 // ---- CSR build on the device: stable counting sort of the rows by list ---------------------------------------------

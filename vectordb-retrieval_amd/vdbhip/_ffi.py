@@ -48,6 +48,7 @@ SIGNATURES = {
     "vdb_device_count": (c_int, [POINTER(c_int)]),
     "vdb_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "vdb_destroy": (c_int, [c_void_p]),
+    "vdb_reset": (c_int, [c_void_p]),
     "vdb_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
     "vdb_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "vdb_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
@@ -124,7 +125,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vdb_abi_version() != 2:
+        if lib.vdb_abi_version() != 3:
             raise ImportError("libvdbhip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -53,6 +53,14 @@ def reserve_workspace(index, params: dict, k: int = 10) -> None:
         index.reserve(n, k)
 
 
+def apply_engine_options(index, params: dict) -> None:
+    """`engine_options: {name: value}` of an algorithm / indexer / searcher config entry are handed to `vdb_set_option`
+    before the corpus is added (include/vdbhip.h lists them; e.g. `stream_panels: 1` for a 768-dim corpus that should
+    occupy ~1.2x instead of ~1.6x its float32 bytes).  An unknown name raises, as the C-ABI does."""
+    for key, value in ((params or {}).get("engine_options") or {}).items():
+        index.set_option(str(key), float(value))
+
+
 class HipExactSearch(BaseAlgorithm):
     """Exact k-NN on one MI355X; same constructor and results as ExactSearch (faiss.IndexFlat)."""
 
@@ -69,6 +77,7 @@ class HipExactSearch(BaseAlgorithm):
         if self.vectors.ndim != 2 or self.vectors.shape[1] != self.dimension:
             raise ValueError(f"expected (n, {self.dimension}) vectors, got {self.vectors.shape}")
         self.index = FlatIndex(self.dimension, self.metric, self.device)
+        apply_engine_options(self.index, self.config)
         self.index.add(self.vectors)
         reserve_workspace(self.index, self.config)
         self.index_built = True
@@ -107,6 +116,7 @@ class HipBruteForceIndexer(BaseIndexer):
                                  metadata={"metric": self.metric, "normalize_vectors": False})
         upload = _safe_normalize(store) if self.metric == "cosine" else store
         index = FlatIndex(self.dimension, "l2" if self.metric == "l2" else "ip", device)
+        apply_engine_options(index, self.params)
         index.add(upload)
         reserve_workspace(index, self.params)
         return IndexArtifact(kind="raw_vectors", data=store,
@@ -133,6 +143,7 @@ class HipLinearSearcher(BaseSearcher):
                 device = _resolve_device(self.params.get("device"), self.params.get("device_ids"))
                 data = _ffi.as_f32_c(store)
                 self._index = FlatIndex(self.dimension, "l2" if self.metric == "l2" else "ip", device)
+                apply_engine_options(self._index, self.params)
                 self._index.add(_safe_normalize(data) if self.metric == "cosine" else data)
                 reserve_workspace(self._index, self.params)
         self._prepared = True

@@ -48,16 +48,23 @@ class FlatIndex:
 
     # -- build --------------------------------------------------------------------------------------
     def add(self, vectors: np.ndarray, id_base: int = 0) -> None:
+        """Append rows (faiss.Index.add): row i of the index, counted over all adds, has id `id_base + i`; every add of
+        one index passes the same `id_base`.  `reset()` empties the index."""
         x = _ffi.as_f32_c(vectors)
         if x.ndim != 2 or x.shape[1] != self.dim:
             raise ValueError(f"expected (n, {self.dim}) vectors, got {x.shape}")
         _ffi.check(self._lib.vdb_add(self._handle(), _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
-        self.ntotal = int(x.shape[0])
+        self.ntotal += int(x.shape[0])
 
     def add_device(self, dev_ptr: int, n: int, id_base: int = 0, stream: int = 0) -> None:
         _ffi.check(self._lib.vdb_add_device(self._handle(), dev_ptr, int(n), int(id_base), stream or None),
                    build_time=True)
-        self.ntotal = int(n)
+        self.ntotal += int(n)
+
+    def reset(self) -> None:
+        """Drop every row (faiss.Index.reset)."""
+        _ffi.check(self._lib.vdb_reset(self._handle()), build_time=True)
+        self.ntotal = 0
 
     # -- search -------------------------------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -67,6 +67,7 @@ class IVFFlatIndex:
         _ffi.check(self._lib.vdb_ivf_train(self._h, self.nlist, _ffi.ptr(x), x.shape[0], int(niter), int(seed),
                                            int(max_points_per_centroid)), build_time=True)
         self.is_trained = True
+        self.ntotal = 0             # (new centroids: rows filed under the old ones are dropped)
 
     def set_centroids(self, centroids: np.ndarray) -> None:
         c = _ffi.as_f32_c(centroids)
@@ -74,6 +75,7 @@ class IVFFlatIndex:
             raise ValueError(f"expected ({self.nlist}, {self.dim}) centroids, got {c.shape}")
         _ffi.check(self._lib.vdb_ivf_set_centroids(self._h, _ffi.ptr(c), self.nlist), build_time=True)
         self.is_trained = True
+        self.ntotal = 0
 
     def centroids(self) -> np.ndarray:
         out = np.empty((self.nlist, self.dim), np.float32)
@@ -81,7 +83,8 @@ class IVFFlatIndex:
         return out
 
     def add(self, x: np.ndarray, id_base: int = 0, list_of_row: Optional[np.ndarray] = None) -> None:
-        """File the rows under the centroids.  `list_of_row` (int32, one list id per row, as `assignment()` returned it
+        """File the rows under the centroids, appending to the lists (faiss.IndexIVF.add; same `id_base` on every add of
+        one index, `reset()` empties it).  `list_of_row` (int32, one list id per row, as `assignment()` returned it
         for this corpus and these centroids) skips the nearest-centroid pass: what loading a persisted index does."""
         x = _ffi.as_f32_c(x)
         if x.ndim != 2 or x.shape[1] != self.dim:
@@ -94,7 +97,12 @@ class IVFFlatIndex:
                 raise ValueError(f"expected {x.shape[0]} list ids, got {lor.shape}")
             _ffi.check(self._lib.vdb_ivf_add_assigned(self._h, _ffi.ptr(x), x.shape[0], int(id_base), _ffi.ptr(lor)),
                        build_time=True)
-        self.ntotal = int(x.shape[0])
+        self.ntotal += int(x.shape[0])
+
+    def reset(self) -> None:
+        """Drop every row; the centroids stay (faiss.IndexIVF.reset)."""
+        _ffi.check(self._lib.vdb_reset(self._h), build_time=True)
+        self.ntotal = 0
 
     def assignment(self) -> np.ndarray:
         out = np.empty((self.ntotal,), np.int32)
