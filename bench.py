@@ -407,7 +407,7 @@ def ivf_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup, nprobes, name
         el, st = timed_device_loop(index, q_t, nq, k, D_t, I_t, stream, steps, warmup, torch)
         ids = I_t.cpu().numpy()
         rows_probed = float(st.get("last_rows_scanned", 0)) or nq * p / float(nlist) * n
-        roof = roofline_of(st, nq, n, d, name, ivf_rows_probed=rows_probed)
+        roof = roofline_of(st, nq, n, d, name, ivf_rows_probed=rows_probed, traffic_key=f"{name}_nprobe{p}")
         roof["hbm_equiv"] = {"bound": "hbm", "achieved": round(4.0 * d * rows_probed / (roof["kernel_ms"] * 1e-3) / 1e9, 1),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "note": "SURVEY 8(d): 4*D bytes x (query, row) pairs / scan time -- what a per-query list "
@@ -536,7 +536,7 @@ def serving_leg(vdbhip, torch, dev, local_rank, stream, index, q_t, k, n, d, tag
     return leg
 
 
-def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
+def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None, traffic_key=None):
     """MFMA roofline of the dominant kernel from the HIP-event time the library recorded on the search stream."""
     scan_ms = float(st["last_scan_ms"])
     i8 = int(st.get("scan_dtype", 0)) == 1
@@ -557,7 +557,7 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None):
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         try:
-            ent = json.loads(pmc.read_text()).get(workload + ("_i8" if i8 else ""), {})
+            ent = json.loads(pmc.read_text()).get(traffic_key or (workload + ("_i8" if i8 else "")), {})
             traffic, source = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:  # noqa: BLE001
             pass

@@ -351,7 +351,11 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
 
     // A wave whose 64 query columns are all padding (the last query tile of a batch that is not a multiple of 512)
     // only keeps staging and the barriers going: its partner on the SIMD gets the matrix pipe to itself.
-    if (!ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid) {
+    // Items mode: the same for a wave whose 64 slots are all padding (the last item of a list) -- with it a large slot
+    // group costs traffic-free padding only, so the lists are streamed fewer times (ivf.inc, waves per work item).
+    bool idle_wave = !ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid;
+    if (ITEMS) idle_wave = __ballot(qa >= 0 || qb >= 0) == 0ull;
+    if (idle_wave) {
         for (int st = 0; st < nstages; ++st) {
             if (st + 1 < nstages) {
                 stage_issue(st + 1, (st & 1) ^ 1);

@@ -237,7 +237,7 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // awaited with s_waitcnt vmcnt((RING - 2) x requests per stage) + s_barrier instead of the vmcnt(0) of __syncthreads().
 template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false, int TB = 0,
           int RING = 2>
-__global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : (ITEMS && NWAVES == 4 && RING <= 4) ? 3 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KS * 64;               // 16-byte vectors per stage
@@ -449,7 +449,14 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : NWAVES >= 4
     if (kDeep) ring_wait();
     else __syncthreads();
 
-    if (!ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid) {   // every query column of this wave is padding: keep staging + barriers going
+    bool idle_wave = !ITEMS && a.nq_valid > 0 && q0 >= a.nq_valid;
+    if (ITEMS) {        // items mode: every slot of this wave is padding (the last item of a list)
+        bool any = false;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) any = any || qslot[cb] >= 0;
+        idle_wave = __ballot(any) == 0ull;
+    }
+    if (idle_wave) {   // every query column of this wave is padding: keep staging + barriers going
         for (int st = 0; st < nstages; ++st) {
             if (kDeep) {
                 ring_issue(st + RING - 1);
