@@ -561,8 +561,12 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None, traffic_key=None):
             traffic, source = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:  # noqa: BLE001
             pass
+    memory_side = {}
+    if traffic and scan_ms > 0:     # what the recorded traffic amounts to at THIS run's kernel time (fabric-side bytes: HBM + Infinity Cache)
+        rate = traffic / (scan_ms * 1e-3) / 1e12
+        memory_side = {"traffic_tb_s": round(rate, 2), "traffic_over_hbm_peak": round(rate / (HBM_PEAK_GBS / 1000.0), 3)}
     return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TOP/s (int8)" if i8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "unit": "TOP/s (int8)" if i8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, **memory_side,
             "traffic_source": (source + " -- a recorded PMC pass of an earlier run of this command, not measured in "
                                "this run") if source else None,
             "kernel_ms": round(scan_ms, 4), "pipeline_ms": round(float(st["last_total_ms"]), 4),

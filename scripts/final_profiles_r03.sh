@@ -31,10 +31,10 @@ prof sift1m --steps 20 --warmup 5 --no-cpu-baseline --no-extras
 python3 $R/scripts/trace_breakdown.py $(find $OUT/sift1m -name '*kernel_trace.csv' | head -1) > $OUT/sift1m_breakdown.txt 2>&1
 for p in 8 32 128; do
   prof ivf$p --workload ivf1024 --nprobe $p --steps 10 --warmup 2 --no-cpu-baseline
-  python3 $R/scripts/trace_breakdown.py $(find $OUT/ivf$p -name '*kernel_trace.csv' | head -1) > $OUT/ivf${p}_breakdown.txt 2>&1
+  python3 $R/scripts/trace_breakdown.py $(find $OUT/ivf$p -name '*kernel_trace.csv' | head -1) ivf_select > $OUT/ivf${p}_breakdown.txt 2>&1
 done
 prof msmarco_ivf --workload msmarco_ivf --steps 10 --warmup 2 --no-cpu-baseline
-python3 $R/scripts/trace_breakdown.py $(find $OUT/msmarco_ivf -name '*kernel_trace.csv' | head -1) > $OUT/msmarco_ivf_breakdown.txt 2>&1
+python3 $R/scripts/trace_breakdown.py $(find $OUT/msmarco_ivf -name '*kernel_trace.csv' | head -1) ivf_select > $OUT/msmarco_ivf_breakdown.txt 2>&1
 if [ "${1:-}" != "quick" ]; then
   prof gaussian1m --workload gaussian1m --steps 20 --warmup 5 --no-cpu-baseline
   prof glove --workload glove1.2m --steps 20 --warmup 5 --no-cpu-baseline

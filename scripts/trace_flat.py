@@ -6,7 +6,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "refine_list_kernel" in n]
+idx = [i for i, n in enumerate(names) if "refine_tail_kernel" in n or "refine_list_kernel" in n]
 sel = idx[-10:-2]
 agg, spans = collections.OrderedDict(), []
 for s in sel:

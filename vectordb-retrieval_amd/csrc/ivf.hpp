@@ -77,12 +77,12 @@ struct IvfFallbackArgs {
 };
 
 template <int KPL>
-__global__ __launch_bounds__(256) void ivf_fallback_kernel(IvfFallbackArgs a) {
+__device__ __forceinline__ void ivf_fallback_body(const IvfFallbackArgs &a, unsigned block, unsigned nblocks) {
     const int64_t count = *a.fb_count;
     if (count <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int64_t waves = (int64_t)gridDim.x * 4;
-    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t waves = (int64_t)nblocks * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(block * 4 + (threadIdx.x >> 6)));
     int64_t S = waves / count;
     if (S > a.max_split) S = a.max_split;
     if (S > a.cap_units / count) S = a.cap_units / count;
@@ -130,6 +130,13 @@ __global__ __launch_bounds__(256) void ivf_fallback_kernel(IvfFallbackArgs a) {
         if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
         else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
     }
+}
+
+// the tail of an IVF search in one launch (as refine_tail_kernel): fallback workgroups first, then the work lists
+template <int KPL>
+__global__ __launch_bounds__(256) void ivf_tail_kernel(RefineListArgs la, IvfFallbackArgs fa, unsigned fb_blocks) {
+    if (blockIdx.x < fb_blocks) ivf_fallback_body<KPL>(fa, blockIdx.x, fb_blocks);
+    else refine_list_body<KPL>(la, blockIdx.x - fb_blocks);
 }
 
 // ---- CSR build: xperm[i] = x[perm[i]], ids[i] = id_base + perm[i] (src_ids: ids[i] = src_ids[perm[i]], the append) ---

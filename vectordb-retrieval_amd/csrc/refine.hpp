@@ -224,9 +224,9 @@ __device__ __forceinline__ void refine_list_dot8(const RefineListArgs &a, int64_
 }
 
 template <int KPL>
-__global__ __launch_bounds__(256) void refine_list_kernel(RefineListArgs a) {
+__device__ __forceinline__ void refine_list_body(const RefineListArgs &a, unsigned block) {
     const int lane = threadIdx.x & 63;
-    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(block * 4 + (threadIdx.x >> 6)));
     if (q >= a.nq) return;
     if (a.fallback[q]) return;
     const float *qptr = a.c.Q + (size_t)q * a.c.D4;
@@ -283,12 +283,12 @@ struct RefineFallbackArgs {
 };
 
 template <int KPL>
-__global__ __launch_bounds__(256) void refine_fallback_kernel(RefineFallbackArgs a) {
+__device__ __forceinline__ void refine_fallback_body(const RefineFallbackArgs &a, unsigned block, unsigned nblocks) {
     const int64_t count = *a.fb_count;
     if (count <= 0) return;
     const int lane = threadIdx.x & 63;
-    const int64_t waves = (int64_t)gridDim.x * 4;
-    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t waves = (int64_t)nblocks * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(block * 4 + (threadIdx.x >> 6)));
     int64_t S = waves / count;
     if (S > a.max_split) S = a.max_split;
     if (S > a.cap_units / count) S = a.cap_units / count;
@@ -333,6 +333,15 @@ __global__ __launch_bounds__(256) void refine_fallback_kernel(RefineFallbackArgs
         if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
         else write_topk<KPL>(tk, a.c.metric, nullptr, nullptr, a.okeys + oq, a.oids + oq);
     }
+}
+
+// The tail of a scan-path search in ONE launch: both parts only consume what the select left (work lists | flagged
+// queries) and write disjoint result rows.  The first `fb_blocks` workgroups are the fallback pass (they start first: a
+// flagged query is the long pole; with none flagged they return after one load), the rest re-score the work lists.
+template <int KPL>
+__global__ __launch_bounds__(256) void refine_tail_kernel(RefineListArgs la, RefineFallbackArgs fa, unsigned fb_blocks) {
+    if (blockIdx.x < fb_blocks) refine_fallback_body<KPL>(fa, blockIdx.x, fb_blocks);
+    else refine_list_body<KPL>(la, blockIdx.x - fb_blocks);
 }
 
 // ---- rerank mode: explicit candidate ids per query ---------------------------------------------------
