@@ -10,5 +10,7 @@ for tag in "flat:--nq 1" "ivf8:--nq 1 --ivf 8" "flat64:--nq 64"; do
 done
 cd $R
 timeout -k 10 200 python3 scripts/latency_serving.py > $OUT/latency_plain.txt 2>&1 || echo "latency failed"
+timeout -k 10 200 python3 scripts/latency_serving.py --option fused_stats=0 > $OUT/latency_separate_stats.txt 2>&1 || echo "latency (separate stats) failed"
+timeout -k 10 200 python3 scripts/latency_serving.py > $OUT/latency_plain_b.txt 2>&1 || echo "latency failed"
 timeout -k 10 300 python3 scripts/soak.py > $OUT/soak.txt 2>&1; echo "soak rc=$?"
 tail -3 $OUT/soak.txt

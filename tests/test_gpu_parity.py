@@ -821,3 +821,35 @@ def test_add_appends_like_faiss(vdb, oracle, d, metric, kind):
     np.testing.assert_array_equal(I3, Is)
     np.testing.assert_array_equal(D3, Ds)
     idx.close()
+
+
+@pytest.mark.parametrize("kind", ["bytes", "gauss", "mixed"])
+def test_serving_batches_take_their_statistics_inside_the_prep_kernel(vdb, oracle, kind):
+    """Batches of <= 4096 query values skip the separate statistics dispatch: every workgroup of the prep kernel scans the
+    batch itself (scan_i8.hpp, `fused_stats`).  Both settings give the oracle's bits on every scan the statistics choose
+    between: int8 (byte-valued integer queries), fp16 (real values), exhaustive (a non-finite value)."""
+    n, d, k = 60000, 128, 10
+    rng = np.random.default_rng(77)
+    X = rng.integers(0, 256, (n, d)).astype(np.float32) if kind != "gauss" else rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.integers(0, 256, (40, d)).astype(np.float32) if kind != "gauss" else rng.standard_normal((40, d)).astype(np.float32)
+    if kind == "mixed":
+        Q[3, 5] += 0.5                                   # one non-integer value: the batches that hold it take the fp16 scan
+    Do, Io = oracle.knn(X, Q, k, "l2")
+    idx = vdb.FlatIndex(d, "l2", 0)
+    idx.add(X)
+    for fused in (1, 0):
+        idx.set_option("fused_stats", fused)
+        for nq in (1, 3, 4, 32, 33, 40):                 # 32 x 128 = 4096 values is the last fused size
+            D, I = idx.search(Q[:nq], k)
+            st = idx.stats()
+            assert st["last_path_name"] == "mfma_scan" and st["last_fallback_queries"] == 0, (fused, nq, st)
+            want_i8 = kind == "bytes" or (kind == "mixed" and nq <= 3)
+            assert st["scan_dtype"] == (1 if want_i8 else 0), (fused, nq, st)
+            np.testing.assert_array_equal(I, Io[:nq], err_msg=f"fused={fused} nq={nq}")
+            np.testing.assert_array_equal(D, Do[:nq], err_msg=f"fused={fused} nq={nq}")
+        Qbad = Q[:5].copy()
+        Qbad[2, 7] = np.inf                              # unusable scales: every query of the batch goes the exhaustive way
+        D, I = idx.search(Qbad, k)
+        assert idx.stats()["last_fallback_queries"] == 5
+        np.testing.assert_array_equal(I[[0, 1, 3, 4]], Io[[0, 1, 3, 4]])
+    idx.close()

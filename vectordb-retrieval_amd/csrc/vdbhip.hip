@@ -182,6 +182,7 @@ struct vdb_index_s {
     // option "stream_panels" (D > 128, takes effect at the next add): the fp16 panels are NOT kept -- every search converts
     // the float32 rows slab by slab into one scratch slab and scans it (search_flat.inc).  Halves the footprint of a
     // non-fp16-exact corpus (the float32 rows must stay for the exact refine) at the price of one conversion pass per batch.
+    int no_fused_stats = 0;                  // option "fused_stats" = 0 (A/B): small batches keep the separate statistics dispatch
     int stream_panels_opt = 0;
     int64_t stream_slab_rows = 0;            // option "stream_slab_rows" (0 = default)
     bool panels_streamed = false;
@@ -914,6 +915,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "stream_panels") {  // D > 128, next add: 0 keep the fp16 panels resident | 1 convert them per search
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "stream_panels must be 0 or 1");
             h->stream_panels_opt = (int)value;
+        } else if (k == "fused_stats") {     // 1 (default) | 0: separate query_stats_kernel for every batch size (A/B)
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "fused_stats must be 0 or 1");
+            h->no_fused_stats = value == 0;
         } else if (k == "stream_slab_rows") {  // rows of the scratch slab of a streamed index (0 = default 1 280 000)
             if (value < 0) throw Error(VDB_ERR_INVALID, "stream_slab_rows must be >= 0");
             h->stream_slab_rows = value;
