@@ -97,7 +97,7 @@ __device__ __forceinline__ void ivf_fallback_body(const IvfFallbackArgs &a, unsi
         for (int p = split; p < a.nprobe; p += (int)S) {
             const int64_t l = a.probes[(size_t)q * a.nprobe + p];
             if (l < 0) continue;
-            scan_rows<KPL>(tk, a.c, qptr, a.offsets[l], a.offsets[l + 1]);
+            scan_rows<KPL, 4>(tk, a.c, qptr, a.offsets[l], a.offsets[l + 1]);      // (4 loads in flight: see refine_fallback_body)
         }
         const size_t oq = (size_t)q * a.c.k;
         if (S == 1) {
@@ -134,7 +134,7 @@ __device__ __forceinline__ void ivf_fallback_body(const IvfFallbackArgs &a, unsi
 
 // the tail of an IVF search in one launch (as refine_tail_kernel): fallback workgroups first, then the work lists
 template <int KPL>
-__global__ __launch_bounds__(256) void ivf_tail_kernel(RefineListArgs la, IvfFallbackArgs fa, unsigned fb_blocks) {
+__global__ __launch_bounds__(256, (KPL == 1 ? 6 : KPL == 2 ? 5 : 1)) void ivf_tail_kernel(RefineListArgs la, IvfFallbackArgs fa, unsigned fb_blocks) {
     if (blockIdx.x < fb_blocks) ivf_fallback_body<KPL>(fa, blockIdx.x, fb_blocks);
     else refine_list_body<KPL>(la, blockIdx.x - fb_blocks);
 }

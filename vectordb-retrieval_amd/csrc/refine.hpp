@@ -300,7 +300,9 @@ __device__ __forceinline__ void refine_fallback_body(const RefineFallbackArgs &a
         const int64_t q = a.fb_list[f];
         WaveTopK<KPL> tk;
         tk.init(a.c.k);
-        scan_rows<KPL>(tk, a.c, a.c.Q + (size_t)q * a.c.D4, (int64_t)split * rows_per_split, (int64_t)(split + 1) * rows_per_split);
+        // (4 row loads in flight, not 16: this body shares its kernel with the work-list refine, whose occupancy -- 71 VGPRs
+        //  alone, 136 with a 16-deep exhaustive scan beside it -- is what its gather-bound time hangs on)
+        scan_rows<KPL, 4>(tk, a.c, a.c.Q + (size_t)q * a.c.D4, (int64_t)split * rows_per_split, (int64_t)(split + 1) * rows_per_split);
         const size_t oq = (size_t)q * a.c.k;
         if (S == 1) {
             if (a.D) write_topk<KPL>(tk, a.c.metric, a.D + oq, a.I + oq, nullptr, nullptr);
@@ -339,7 +341,7 @@ __device__ __forceinline__ void refine_fallback_body(const RefineFallbackArgs &a
 // queries) and write disjoint result rows.  The first `fb_blocks` workgroups are the fallback pass (they start first: a
 // flagged query is the long pole; with none flagged they return after one load), the rest re-score the work lists.
 template <int KPL>
-__global__ __launch_bounds__(256) void refine_tail_kernel(RefineListArgs la, RefineFallbackArgs fa, unsigned fb_blocks) {
+__global__ __launch_bounds__(256, (KPL == 1 ? 6 : KPL == 2 ? 5 : 1)) void refine_tail_kernel(RefineListArgs la, RefineFallbackArgs fa, unsigned fb_blocks) {
     if (blockIdx.x < fb_blocks) refine_fallback_body<KPL>(fa, blockIdx.x, fb_blocks);
     else refine_list_body<KPL>(la, blockIdx.x - fb_blocks);
 }
