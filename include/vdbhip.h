@@ -191,6 +191,8 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *     "small_batch"     1 (default): batches of <= 512 queries are scanned with finer row chunks and, up to 256 queries,
  *                       1 / 2 / 4-wave workgroups, so that the grid still covers the chip; D > 128: waves without queries
  *                       only stage panels, <= 16 queries keep their query block in LDS | 0 the batch shape for every size
+ *     "fused_stats"     1 (default): batches of <= 4096 query values (serving shapes) take their statistics inside the
+ *                       query-operand kernel, one dependent dispatch less | 0 a separate statistics dispatch for every size
  *     "ivf_min_batch"   smallest query batch the list-major MFMA scan of the IVF index serves (default 1); smaller ones
  *                       take the exact per-query list scan
  *     "graph"           0 (default) | 1: a vdb_search_device / vdb_search_partial_device / vdb_ivf_search*_device call of
