@@ -205,6 +205,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       per 1 / 2 tiles)
  *     "i8_group"        8 (default) | 4 rows per select group of the flat int8 scan
  *     "i8_ring"         0 auto (4) | 2 | 4 | 8 LDS staging stages of the serving-shaped and IVF int8 scans
+ *     "i8_nt"           0 (default) / 2: the serving-shaped int8 scan stages its panels with non-temporal loads | 1 off
  *     "ivf_nw"          0 auto | 2 / 4 / 8 waves per IVF work item
  *     "ivf_bt"          0 auto | 4 (64-row bins) | 16 (the largest: one bin per half of a 256-row span)
  *     "ivf_tps"         D > 128, takes effect at the next vdb_ivf_add: 0 auto | 16 (256-row spans, 64-row bins) | 64

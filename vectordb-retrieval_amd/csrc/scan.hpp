@@ -266,7 +266,8 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
                 reinterpret_cast<__attribute__((address_space(3))) void *>(
                     static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
-                16, 0, 0);
+                16, 0, (NWAVES <= 2 && !ITEMS) ? 2 : 0);     // (1- / 2-wave workgroups = serving shapes, one query tile: every panel byte
+                                                              //  is read once per search -> non-temporal, as scan_i8_kernel's AUX)
         }
 #pragma unroll
         for (int i = 0; i < kBiasLoads; ++i) {

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rs, reinterpret_cast<__attribute__((address_space(3))) void *>(
                         static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
-                16, lane16, ABL == 3 ? p * 1024 : (t * KS + ks) * 1024, 0, 0);
+                16, lane16, ABL == 3 ? p * 1024 : (t * KS + ks) * 1024, 0, NARROW ? 2 : 0);   // (NARROW: one query tile, panels read once per search -> non-temporal)
         }
     };
 

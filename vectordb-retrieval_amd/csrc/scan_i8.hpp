@@ -236,7 +236,7 @@ __device__ __forceinline__ void mfma_phase_i8(const int4v (&fr)[KS], const int4v
 // LDS-DMA as well (no register staging), every wave issues the same number of requests per stage, and a stage is
 // awaited with s_waitcnt vmcnt((RING - 2) x requests per stage) + s_barrier instead of the vmcnt(0) of __syncthreads().
 template <int KS, int ST, int CB, int NWAVES = 8, int BT = 16, bool ITEMS = false, int G = 8, bool DBG = false, int TB = 0,
-          int RING = 2>
+          int RING = 2, int AUX = 0>
 __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : (ITEMS && NWAVES == 4 && RING <= 4) ? 3 : NWAVES >= 4 ? 2 : 1)) void scan_i8_kernel(ScanI8Args a) {
     constexpr int GPT = 16 / G;                           // groups per (tile, column block): quads 4, octs 2
     constexpr int NT = NWAVES * 64;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : (ITEMS && N
                 reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(g)),
                 reinterpret_cast<__attribute__((address_space(3))) void *>(
                     static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
-                16, 0, 0);
+                16, 0, AUX);       // (AUX = 2: non-temporal -- scan copies larger than the Infinity Cache, read once per search)
         }
         if (kDeep) {        // accumulator inits of the stage: ST / 2 pieces of 64 ints (two tiles each), by LDS-DMA too; every
                             // wave issues kBiasPieces of them (a piece requested twice lands twice with the same bytes)

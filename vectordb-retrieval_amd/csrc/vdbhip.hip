@@ -143,6 +143,7 @@ struct vdb_index_s {
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    int i8_nt = 0;                           // option "i8_nt": non-temporal staging loads of the serving-shaped int8 scan (0 auto, 1 never, 2 always)
     int i8_ring = 0;                         // option "i8_ring": LDS staging stages of the streaming-shaped int8 scans (0 auto, 2, 4, 8)
     // option "graph": a device-resident search that repeats with the same shape and buffers (a serving loop) is captured
     // into a hipGraph on its second call and replayed from the third (graph_or_run)
@@ -948,6 +949,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
+        } else if (k == "i8_nt") {
+            if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "i8_nt must be 0, 1 or 2");
+            h->i8_nt = (int)value;
         } else if (k == "i8_ring") {           // staging ring of the serving-shaped / IVF int8 scans: 0 auto, 2 (double buffer), 4, 8
             if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_ring must be 0, 2, 4 or 8");
             h->i8_ring = (int)value;
