@@ -722,14 +722,32 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sv[e]));
 #pragma unroll
     for (int e = 0; e < VPL; ++e) v[e] = (e * 64 + lane < nsb) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
-    // k-th smallest by bisection from the top bit
+    // k-th smallest by bisection from the top bit.  Any U >= tau is a valid threshold (it only lets more bins through), so
+    // with many values per lane (VPL >= 4) and k <= 64 the bisection runs on each lane's TWO smallest values only: their
+    // k-th smallest is >= tau (a subset), and equal to it unless three of the k best superbins share a lane -- 2 ballots per
+    // step instead of VPL (a single query's select is one wave walking this chain alone: 15 us of a 67 us search).
     unsigned ans = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned trial = ans | ((1u << bit) - 1u);
-        int cnt = 0;
+    if (VPL >= 4 && a.k <= 64) {
+        unsigned lo0 = 0xFFFFFFFFu, lo1 = 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < VPL; ++e) cnt += __popcll(__ballot(v[e] <= trial));
-        if (cnt < a.k) ans |= (1u << bit);
+        for (int e = 0; e < VPL; ++e) {
+            const unsigned x = v[e];
+            lo1 = min(lo1, max(lo0, x));
+            lo0 = min(lo0, x);
+        }
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = ans | ((1u << bit) - 1u);
+            const int cnt = __popcll(__ballot(lo0 <= trial)) + __popcll(__ballot(lo1 <= trial));
+            if (cnt < a.k) ans |= (1u << bit);
+        }
+    } else {
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = ans | ((1u << bit) - 1u);
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) cnt += __popcll(__ballot(v[e] <= trial));
+            if (cnt < a.k) ans |= (1u << bit);
+        }
     }
     const float tau = unsortable_f32(ans);
     const int i8_mode = a.info->i8_mode;              // (read ONCE: inside the loops below every use would be a fresh global load)
@@ -742,18 +760,24 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     if (!force_fb) {
+        // second minimum and span of every superbin, requested up front and unconditionally (clamped index): under
+        // `if (active)` each of the VPL iterations below paid its own memory round trip
+        float sm2v[VPL];
+        int spanv[VPL];
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) sm2v[e] = a.sb_m2[(size_t)min(e * 64 + lane, nsb - 1) * a.Qpad + q];
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) spanv[e] = a.direct_rows ? 0 : a.sb_span[(size_t)min(e * 64 + lane, nsb - 1) * a.Qpad + q];
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sm2v[e]), "+v"(spanv[e]));
 #pragma unroll
         for (int e = 0; e < VPL; ++e) {
             const int s = e * 64 + lane;
             const bool in = s < nsb;
             const float m1 = in ? unsortable_f32(v[e]) : __builtin_inff();
             const bool active = in && (m1 <= that);
-            float sm2 = __builtin_inff();
-            int sspan = 0;
-            if (active) {
-                sm2 = a.sb_m2[(size_t)s * a.Qpad + q];
-                if (!a.direct_rows) sspan = a.sb_span[(size_t)s * a.Qpad + q];
-            }
+            const float sm2 = active ? sm2v[e] : __builtin_inff();
+            const int sspan = active ? spanv[e] : 0;
             if (a.direct_rows) {   // the superbin is a bin of direct_rows consecutive rows: candidate quad or re-scan, no walk
                 const int row0 = (s / dbps) * kBinRows + (s % dbps) * a.direct_rows;
                 const bool single = active && !(sm2 <= that), deep = active && !single;
