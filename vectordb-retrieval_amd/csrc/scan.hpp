@@ -324,8 +324,8 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         const size_t o = (size_t)((span * 2 + h) * BPS + bt) * out_pitch + out_col;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            a.bin_m1[o + cb * 32] = m1[cb];
-            a.bin_m2[o + cb * 32] = m2[cb];
+            __builtin_nontemporal_store(m1[cb], a.bin_m1 + o + cb * 32);     // (written once, read sparsely by the select: they
+            __builtin_nontemporal_store(m2[cb], a.bin_m2 + o + cb * 32);     //  should not push the panels out of L2 -- scan_i8.hpp)
             M2[cb] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[cb], M2[cb], m1[cb]), m2[cb]);
             if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
             M1[cb] = __builtin_fminf(M1[cb], m1[cb]);

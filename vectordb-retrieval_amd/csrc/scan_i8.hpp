@@ -418,8 +418,11 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES > 8 ? NWAVES / 4 : (ITEMS && N
             if (!a.abl_no_bins)
 #endif
             {
-                a.bin_m1[o + cb * 32] = __int_as_float(m1[cb]);
-                a.bin_m2[o + cb * 32] = __int_as_float(m2[cb]);
+                // (non-temporal: 339 MB of bins per 10k-query batch on 1M rows are written once and read sparsely by the select,
+                //  while the 128 MB of panels are re-read by every query tile from L2 / the Infinity Cache; A/B in alternating
+                //  processes on one box: 9.19 - 9.28 -> 9.27 - 9.34 M QPS)
+                __builtin_nontemporal_store(__int_as_float(m1[cb]), a.bin_m1 + o + cb * 32);
+                __builtin_nontemporal_store(__int_as_float(m2[cb]), a.bin_m2 + o + cb * 32);
             }
             M2[cb] = imin(imed3(M1[cb], M2[cb], m1[cb]), m2[cb]);
             if (m1[cb] < M1[cb]) Ms[cb] = (int)span;
