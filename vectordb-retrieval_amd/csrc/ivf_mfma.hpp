@@ -438,7 +438,7 @@ struct IvfSelectArgs {
                                   //   2 (32-row-tile scans): one run per lane half, [half][span][bin of the half], every run
                                   //   padded to a multiple of 4 entries (the padding holds +inf): see ivf_bins_of_list
     int32_t *cand_rows, *rescan_rows, *counts, *fallback;
-    int32_t *fb_list, *fb_count;  // flagged queries, compacted for ivf_fallback_kernel (ivf.hpp)
+    int32_t *fb_list, *fb_count;  // flagged queries, compacted for ivf_fallback_body (ivf.hpp, ivf_tail_kernel)
     unsigned long long *stat_counters;  // [3] candidates, rescans, fallback queries
 };
 

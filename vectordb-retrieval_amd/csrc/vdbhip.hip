@@ -100,7 +100,7 @@ inline QueryBatchInfo *batch_info(Workspace &ws);
 
 struct Workspace {
     DevBuf qpad, qpanels, qpanels8, qrows8, info, eps, bin_m1, bin_m2, bin_m3, bin_m4, bin_m5, sb_m1, sb_m2, sb_span;
-    DevBuf cand, rescan, counts, fallback, fb_list, fb_done /* arrival counters of refine_fallback_kernel */, small;  // small: fb_count (int) + 2 stat counters
+    DevBuf cand, rescan, counts, fallback, fb_list, fb_done /* arrival counters of refine_fallback_body (refine_tail_kernel) */, small;  // small: fb_count (int) + 2 stat counters
     DevBuf dense;            // nq x Npad raw scores of the small-corpus path
     DevBuf pkeys, pids;      // partial lists of the exhaustive / fallback passes
     DevBuf stage_q, stage_d, stage_i;  // host-API staging
