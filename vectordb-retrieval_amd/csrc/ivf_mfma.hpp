@@ -515,6 +515,13 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         unsigned low0 = 0xFFFFFFFFu, low1 = 0xFFFFFFFFu;     // the two smallest keys this lane has seen
         // (four entries per lane and round: their probe look-ups and loads overlap -- one entry per round left ONE global
         //  load in flight per lane, and at nprobe 128 (2000+ entries per query) this loop ran as long as the list scan)
+        // (a lane's entries ascend by 64: its probe index only moves forward -- one binary search at the start, then a few
+        //  steps along p_off per entry instead of seven LDS reads each; p_off[nprobe] = E ends the walk)
+        int pcur = lane < E ? probe_of(lane) : 0;
+        auto advance = [&](int e) {
+            while (p_off[pcur + 1] <= e) ++pcur;
+            return pcur;
+        };
         for (int e0 = lane; e0 < E; e0 += 256) {
             float raw[4];
 #pragma unroll
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 const int e = e0 + 64 * u;
                 raw[u] = __builtin_inff();
                 if (e < E) {
-                    const int p = probe_of(e);
+                    const int p = advance(e);
                     const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
                     raw[u] = a.bin_m[0][base + (e - p_off[p])];
                 }
@@ -563,6 +570,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         if (!(that < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+        pcur = lane < E ? probe_of(lane) : 0;
         for (int e4 = 0; e4 < E && !fb; e4 += 256) {
           float m1v[4];
           int pv[4];
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
               m1v[u] = __builtin_inff();
               pv[u] = 0;
               if (e < E) {
-                  pv[u] = probe_of(e);
+                  pv[u] = advance(e);
                   if (keep) {
                       m1v[u] = unsortable_f32(vals[e]);
                   } else {
