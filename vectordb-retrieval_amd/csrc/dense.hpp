@@ -249,13 +249,23 @@ __global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_
         unsigned t2 = 0xFFFFFFFFu;
         bool decided = ncand == k;     // exactly k rows within tau + 2 eps: every other row is farther than each of them
         if (!decided) {
-            t2 = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const unsigned trial = t2 | ((1u << bit) - 1u);
-                int cnt = 0;
-                for (int base = 0; base < ncand; base += 64)
-                    cnt += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= trial));
-                if (cnt < k) t2 |= (1u << bit);
+            // exact tau = the k-th smallest candidate key.  `ans` (the k-th smallest of the lanes' M smallest) IS that value
+            // whenever exactly k candidate keys are <= ans -- one counting pass instead of a 32-step bisection whose every
+            // step re-reads the keys from LDS (the usual case; the bisection remains for ties and crowded lanes)
+            int c_ans = 0;
+            for (int base = 0; base < ncand; base += 64)
+                c_ans += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= ans));
+            if (c_ans == k) {
+                t2 = ans;
+            } else {
+                t2 = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned trial = t2 | ((1u << bit) - 1u);
+                    int cnt = 0;
+                    for (int base = 0; base < ncand; base += 64)
+                        cnt += __popcll(__ballot(base + lane < ncand && ckeys[base + lane] <= trial));
+                    if (cnt < k) t2 |= (1u << bit);
+                }
             }
             // A gap wider than 2 eps between the k-th and the (k+1)-th approximate score settles the SET without any exact
             // re-scoring (exact_i <= tau + eps < next - eps <= exact_j; rows outside the candidate list are farther still) --
