@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VDB_ABI_VERSION 3
+#define VDB_ABI_VERSION 4
 
 typedef struct vdb_index_s *vdb_handle;
 
@@ -78,6 +78,8 @@ typedef struct vdb_stats_s {
     int64_t last_rows_scanned; /* IVF: (query, row) pairs scanned by the last search (rows of the probed lists) */
     int64_t upload_blocks;     /* row blocks the last vdb_add / vdb_ivf_add streamed through the pinned staging buffers */
     int64_t graph_replays;     /* searches served by launching the captured hipGraph (option "graph") since the handle was made */
+    int32_t ndevices;          /* shards of the handle: 1, or the ndev of vdb_create_multi (sums / maxima over the shards above) */
+    int32_t reserved0;
 } vdb_stats_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -87,6 +89,23 @@ int vdb_device_count(int *count);
 
 /* ---- flat (brute-force) index -- replaces faiss.IndexFlat(d, metric) (exact_search.py:38) -- */
 int vdb_create(int dim, int metric, int device, vdb_handle *out);
+/* ONE index over several GPUs of the node, driven from ONE process -- the form SURVEY 8b proposed
+ * (`vdb_create(dim, metric, const int *devs, int ndev, ...)`), because the reference's harness is a single process that calls
+ * build_index once and batch_search per batch (src/experiments/experiment_runner.py:329-331, 428-434) on a plugin made from a
+ * `type:` string (src/algorithms/__init__.py:37-47).  The handle is an ordinary vdb_handle:
+ *   vdb_add / vdb_add_device / vdb_ivf_add(_assigned)  cut the rows of a call into ndev contiguous blocks, block s -> devices[s]
+ *                  (SURVEY 8e); ids stay id_base + insertion order, appends work as on one device;
+ *   vdb_search / vdb_ivf_search (+ _device, _partial_device; device pointers = memory of devices[0])  run every shard's partial
+ *                  search on its own device, stream and host thread, gather the packed partials into devices[0] by peer copies
+ *                  over xGMI and merge them there on (float64 key, global id): the result is bit-identical to the
+ *                  single-device index of the same rows, whatever ndev;
+ *   vdb_ivf_train  runs k-means once (on devices[0], over the whole training set); every shard files its rows under the same
+ *                  centroids and probes the same lists;
+ *   vdb_reserve, vdb_stats (sums / maxima over the shards, ndevices), vdb_set_option (forwarded), vdb_reset, vdb_destroy,
+ *   vdb_ivf_set_centroids / _get_centroids / _set_nprobe / _get_assignment  work as on one device.
+ * Not available on such a handle (VDB_ERR_UNSUPPORTED): vdb_rerank(_device), option "graph", the debug hooks.
+ * A device may be listed more than once (several shards on one GPU). */
+int vdb_create_multi(int dim, int metric, const int *devices, int ndev, vdb_handle *out);
 int vdb_destroy(vdb_handle h);
 
 /* replaces index.add(vectors) (exact_search.py:39; modular.py:124-130 keeps the raw matrix):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvdbhip.so does not export {name}"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert lib.vdb_abi_version() == 3
+    assert lib.vdb_abi_version() == 4
     # error plumbing works without a GPU: a null handle is rejected with a message
     st = _ffi.Stats()
     assert lib.vdb_stats(None, ctypes.byref(st)) == _ffi.VDB_ERR_INVALID

@@ -190,3 +190,62 @@ def test_two_gloo_ranks_equal_unsharded(tmp_path, oracle):
                 assert tuple(g[f"shard_{tag}"]) == tuple(g["shard"])
                 assert int(g[f"rows_{tag}"]) == g["shard"][1] - g["shard"][0]      # only its own rows were handed over
         assert shards == [(0, 501), (501, 1001)]
+
+
+# ---- no silent world = 1 ----------------------------------------------------------------
+def test_world_size_without_a_process_group_raises(monkeypatch):
+    """WORLD_SIZE > 1 announced, no process group, no rendezvous variables: an error, never a silent full scan per rank."""
+    from vdbhip.sharded import HipShardedApproximateSearch, HipShardedExactSearch, ensure_process_group
+
+    for var in ("RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    X = np.zeros((16, 4), np.float32)
+    with pytest.raises(RuntimeError, match="WORLD_SIZE=2 but no torch.distributed process group"):
+        HipShardedExactSearch("sh", 4, engine_factory=_OracleEngine).build_index(X)
+    with pytest.raises(RuntimeError, match="WORLD_SIZE=2"):
+        HipShardedApproximateSearch("sh", 4, "IVF2,Flat", engine_factory=_OracleIVFEngine).build_index(X)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert ensure_process_group() == (0, 1)
+    monkeypatch.delenv("WORLD_SIZE")
+    assert ensure_process_group() == (0, 1)
+
+
+def _autoinit_worker(rank, world, port, out_dir):
+    """What a rank of `torchrun ... scripts/run_full_benchmark.py` looks like to the plugin: the launcher's environment,
+    nobody has called init_process_group."""
+    sys.path[:0] = [str(ROOT), str(ROOT / "vectordb-retrieval_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), VDBHIP_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+
+    from vdbhip.sharded import HipShardedExactSearch
+
+    assert not dist.is_initialized()
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((777, 12)).astype(np.float32)
+    Q = rng.standard_normal((5, 12)).astype(np.float32)
+    algo = HipShardedExactSearch("sh", 12, metric="l2", engine_factory=_OracleEngine)
+    algo.build_index(X)
+    try:
+        assert dist.is_initialized() and dist.get_backend() == "gloo" and (algo.rank, algo.world) == (rank, world)
+        d, i = algo.batch_search(Q, k=4)
+        np.savez(Path(out_dir) / f"auto_r{rank}.npz", d=d, i=i, shard=np.array(algo.shard))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_process_group_is_initialised_from_the_launcher_environment(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    mp.spawn(_autoinit_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((777, 12)).astype(np.float32)
+    Q = rng.standard_normal((5, 12)).astype(np.float32)
+    d_ref, i_ref = oracle.knn(X, Q, 4, "l2")
+    for r in range(world):
+        g = np.load(tmp_path / f"auto_r{r}.npz")
+        np.testing.assert_array_equal(g["i"], i_ref)
+        np.testing.assert_array_equal(g["d"], d_ref)
+    assert tuple(np.load(tmp_path / "auto_r1.npz")["shard"]) == (389, 777)

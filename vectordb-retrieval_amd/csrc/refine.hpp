@@ -489,6 +489,9 @@ struct MergeArgs {
     int64_t *I;
     double *okeys;            // ... or partial output (count,k)
     int64_t *oids;
+    // optional (multi-device index, multi.inc): the ids of part p are LOCAL row numbers of shard p; segment table =
+    // [nparts + 1 offsets | (local0, id0) pairs grouped by part, ascending local0]: rows from local0 on have ids from id0 on
+    const int64_t *seg;
 };
 
 template <int KPL>
@@ -512,6 +515,13 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
                 id = a.pids[o];
                 key = sortable_u64(a.pkeys[o]);
                 valid = id >= 0;
+                if (valid && a.seg) {          // local row of shard p -> global id (the map is monotone: ties keep their order)
+                    const int64_t *pairs = a.seg + a.nparts + 1;
+                    int64_t e = a.seg[p];
+                    const int64_t e1 = a.seg[p + 1];
+                    while (e + 1 < e1 && pairs[2 * (e + 1)] <= id) ++e;
+                    id = pairs[2 * e + 1] + (id - pairs[2 * e]);
+                }
             }
             tk.offer(key, id, valid);
         }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,16 +60,18 @@ struct DevBuf {
         if (bytes <= cap) return;
         if (borrowed) throw Error(VDB_ERR_INVALID, "internal: a borrowed device buffer cannot grow");
         void *old = p;
-        p = nullptr;
-        cap = 0;
+        const size_t old_cap = cap;
         g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
         const size_t want = bytes + std::min<size_t>(bytes >> 3, (size_t)256 << 20);
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            p = nullptr;
-            if (old) (void)hipFree(old);
+        void *fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, want);
+        if (e != hipSuccess) {              // the old buffer stays as it was: a failed append leaves the index intact
+            (void)hipGetLastError();
+            p = old;
+            cap = old_cap;
             throw Error(VDB_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
         }
+        p = fresh;
         cap = want;
         if (old && keep) e = hipMemcpy(p, old, keep, hipMemcpyDeviceToDevice);
         if (old) (void)hipFree(old);
@@ -126,7 +129,11 @@ inline QueryBatchInfo *batch_info(Workspace &ws) {        // inside ws.small (co
 
 }  // namespace
 
+struct vdb_multi_s;           // multi.inc: the shards, streams and host threads of a multi-device handle
+
 struct vdb_index_s {
+    vdb_multi_s *multi = nullptr;            // non-null: a multi-device handle (vdb_create_multi); device = the primary device,
+                                             // N / id_base / built / ivf_built / nlist / nprobe describe the whole index
     int device = 0;
     int dim = 0, D4 = 0, ksteps = 0, metric = 0;
     int64_t N = 0, Npad = 0, id_base = 0;
@@ -475,13 +482,22 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     graph_reset(h);
     if (n > 2147483647ll - 1024) throw Error(VDB_ERR_UNSUPPORTED, "more than 2^31 rows per shard");
     h->built = false;
+    h->ivf_built = false;              // (rows filed by vdb_ivf_add sat in list order under a CSR that no longer describes x32)
+    h->ivf_list_of_row.clear();
     h->N = n;
     h->id_base = id_base;
-    if (n > 0) {
-        h->x32.reserve((size_t)n * h->D4 * sizeof(float));
-        ingest_rows(h, 0, x_dev_or_host, on_device, n, st);
+    try {
+        if (n > 0) {
+            h->x32.reserve((size_t)n * h->D4 * sizeof(float));
+            ingest_rows(h, 0, x_dev_or_host, on_device, n, st);
+        }
+        build_derived(h, st);
+    } catch (...) {                    // a failed build leaves an EMPTY index (the next add starts over; a search says "not built")
+        h->N = 0;
+        h->built = false;
+        h->scan_ok = false;
+        throw;
     }
-    build_derived(h, st);
 }
 
 void require_same_id_base(const vdb_index_s *h, int64_t id_base) {
@@ -493,7 +509,7 @@ void require_same_id_base(const vdb_index_s *h, int64_t id_base) {
 
 // vdb_add / vdb_add_device: APPEND, as faiss.Index.add does (the first add of an empty index is build_index)
 void append_rows(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base, hipStream_t st) {
-    if (!h->built || h->N == 0) {
+    if (h->N == 0 || h->ivf_built) {      // (rows filed by vdb_ivf_add are replaced: they sit in list order, not insertion order)
         build_index(h, x_dev_or_host, on_device, n, id_base, st);
         return;
     }
@@ -502,11 +518,29 @@ void append_rows(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     if (n == 0) return;
     if (h->N + n > 2147483647ll - 1024) throw Error(VDB_ERR_UNSUPPORTED, "more than 2^31 rows per shard");
     graph_reset(h);
-    h->built = false;
     VDB_HIP(hipDeviceSynchronize());                        // (searches of the rows about to move may still run)
     const int64_t N0 = h->N;
-    h->x32.grow((size_t)(N0 + n) * h->D4 * sizeof(float), (size_t)N0 * h->D4 * sizeof(float));
-    ingest_rows(h, N0, x_dev_or_host, on_device, n, st);
+    // the scan copies are re-derived from the float32 rows anyway: free them first, so that the peak is old rows + grown rows
+    // (not that plus the copies), and on failure rebuild them from the old rows -- the append is atomic (N, ids and results
+    // as before the call)
+    DevBuf *derived[] = {&h->panels, &h->panels8, &h->rows8, &h->rowstat8, &h->bias, &h->bias8, &h->slab};
+    for (auto b : derived) b->release();
+    h->built = false;
+    try {
+        h->x32.grow((size_t)(N0 + n) * h->D4 * sizeof(float), (size_t)N0 * h->D4 * sizeof(float));
+        ingest_rows(h, N0, x_dev_or_host, on_device, n, st);
+    } catch (...) {
+        (void)hipGetLastError();
+        h->N = N0;
+        try {
+            build_derived(h, st);
+        } catch (...) {                // not even the old copies fit any more: the index is emptied, loudly
+            h->N = 0;
+            h->built = false;
+            h->scan_ok = false;
+        }
+        throw;
+    }
     h->N = N0 + n;
     build_derived(h, st);                                   // (scan copies are rebuilt from the float32 rows: 0.3 s per 12.5M x 768)
 }
@@ -533,6 +567,25 @@ int guarded(F &&f) {
 vdb_index_s *check(vdb_handle h) {
     if (!h) throw Error(VDB_ERR_INVALID, "null handle");
     return h;
+}
+
+// multi-device handles (multi.inc)
+void multi_destroy(vdb_index_s *m);
+void multi_reset(vdb_index_s *m);
+void multi_add(vdb_index_s *m, const float *x, bool on_device, int64_t n, int64_t id_base, hipStream_t user_stream, bool ivf,
+               const int32_t *given);
+void multi_search(vdb_index_s *m, const float *q, bool device_api, int64_t nq, int k, float *D, int64_t *I, double *PK,
+                  int64_t *PI, hipStream_t user_stream, bool ivf);
+void multi_reserve(vdb_index_s *m, int64_t nq, int k);
+void multi_stats(vdb_index_s *m, vdb_stats_t *out);
+void multi_set_option(vdb_index_s *m, const char *key, double value);
+void multi_set_centroids(vdb_index_s *m, const float *c_host, int nlist);
+void multi_train(vdb_index_s *m, int nlist, const float *x_host, int64_t n, int niter, uint64_t seed, int mppc);
+void multi_get_assignment(vdb_index_s *m, int32_t *out);
+vdb_index_s *multi_first_shard(vdb_index_s *m);
+void multi_for_each_shard(vdb_index_s *m, const std::function<void(vdb_index_s *)> &f);
+[[noreturn]] inline void multi_unsupported(const char *what) {
+    throw Error(VDB_ERR_UNSUPPORTED, std::string(what) + " is not available on a multi-device index (vdb_create_multi)");
 }
 
 }  // namespace
@@ -581,6 +634,11 @@ int vdb_create(int dim, int metric, int device, vdb_handle *out) {
 int vdb_destroy(vdb_handle h) {
     return guarded([&] {
         if (!h) return;
+        if (h->multi) {
+            multi_destroy(h);
+            delete h;
+            return;
+        }
         set_device(h->device);
         (void)hipDeviceSynchronize();
         DevBuf *all[] = {&h->x32, &h->xnorm2, &h->panels, &h->slab, &h->bias, &h->stats, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8, &h->ivf_offsets, &h->ivf_ids,
@@ -606,6 +664,7 @@ int vdb_add(vdb_handle hh, const float *x_host, int64_t n, int64_t id_base) {
     return guarded([&] {
         auto *h = check(hh);
         if (n > 0 && !x_host) throw Error(VDB_ERR_INVALID, "null corpus pointer");
+        if (h->multi) return multi_add(h, x_host, false, n, id_base, nullptr, false, nullptr);
         set_device(h->device);
         append_rows(h, x_host, false, n, id_base, nullptr);
     });
@@ -614,6 +673,7 @@ int vdb_add(vdb_handle hh, const float *x_host, int64_t n, int64_t id_base) {
 int vdb_reset(vdb_handle hh) {
     return guarded([&] {
         auto *h = check(hh);
+        if (h->multi) return multi_reset(h);
         set_device(h->device);
         VDB_HIP(hipDeviceSynchronize());
         graph_reset(h);
@@ -623,6 +683,11 @@ int vdb_reset(vdb_handle hh) {
         h->ivf_built = false;
         h->ivf_list_of_row.clear();
         h->ivf_offsets_host.clear();
+        // faiss.Index.reset frees its storage: so do we (rows, scan copies, CSR arrays; the workspace and an IVF index's
+        // centroids stay) -- a caller that resets a 38 GB shard to load another corpus gets the memory back
+        DevBuf *rows[] = {&h->x32, &h->xnorm2, &h->panels, &h->slab, &h->bias, &h->panels8, &h->bias8, &h->rows8, &h->rowstat8,
+                          &h->ivf_offsets, &h->ivf_ids, &h->ivf_list_pspan0, &h->ivf_span_row0, &h->ivf_span_valid};
+        for (auto b : rows) b->release();
     });
 }
 
@@ -630,6 +695,7 @@ int vdb_add_device(vdb_handle hh, const float *x_dev, int64_t n, int64_t id_base
     return guarded([&] {
         auto *h = check(hh);
         if (n > 0 && !x_dev) throw Error(VDB_ERR_INVALID, "null corpus pointer");
+        if (h->multi) return multi_add(h, x_dev, true, n, id_base, as_stream(stream), false, nullptr);
         set_device(h->device);
         append_rows(h, x_dev, true, n, id_base, as_stream(stream));
     });
@@ -645,6 +711,7 @@ int vdb_search(vdb_handle hh, const float *q_host, int64_t nq, int k, float *D, 
             if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
             return;
         }
+        if (h->multi) return multi_search(h, q_host, false, nq, k, D, I, nullptr, nullptr, nullptr, false);
         set_device(h->device);
         Workspace &ws = h->ws;
         ws.stage_q.reserve((size_t)nq * h->dim * sizeof(float));
@@ -665,6 +732,7 @@ int vdb_search_device(vdb_handle hh, const float *q_dev, int64_t nq, int k, floa
     return guarded([&] {
         auto *h = check(hh);
         if (nq > 0 && (!D_dev || !I_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
+        if (h->multi) return multi_search(h, q_dev, true, nq, k, D_dev, I_dev, nullptr, nullptr, as_stream(stream), false);
         set_device(h->device);
         vdb_index_s::GraphKey key;
         key.q = q_dev; key.o1 = D_dev; key.o2 = I_dev; key.nq = nq; key.k = k; key.kind = 1; key.st = as_stream(stream);
@@ -677,6 +745,7 @@ int vdb_search_partial_device(vdb_handle hh, const float *q_dev, int64_t nq, int
     return guarded([&] {
         auto *h = check(hh);
         if (nq > 0 && (!keys_dev || !ids_dev)) throw Error(VDB_ERR_INVALID, "null output pointer");
+        if (h->multi) return multi_search(h, q_dev, true, nq, k, nullptr, nullptr, keys_dev, ids_dev, as_stream(stream), false);
         set_device(h->device);
         vdb_index_s::GraphKey key;
         key.q = q_dev; key.o1 = keys_dev; key.o2 = ids_dev; key.nq = nq; key.k = k; key.kind = 2; key.st = as_stream(stream);
@@ -764,6 +833,7 @@ int vdb_rerank_device(vdb_handle hh, const float *q_dev, int64_t nq, const int64
                       float *D_dev, int64_t *I_dev, void *stream) {
     return guarded([&] {
         auto *h = check(hh);
+        if (h->multi) multi_unsupported("vdb_rerank_device");
         set_device(h->device);
         rerank_device_impl(h, q_dev, nq, cand_dev, ncand, k, D_dev, I_dev, as_stream(stream));
     });
@@ -773,6 +843,7 @@ int vdb_rerank(vdb_handle hh, const float *q_host, int64_t nq, const int64_t *ca
                int64_t *I) {
     return guarded([&] {
         auto *h = check(hh);
+        if (h->multi) multi_unsupported("vdb_rerank");
         if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
         if (nq <= 0) {
             if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
@@ -803,8 +874,10 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
     return guarded([&] {
         auto *h = check(hh);
         if (!out) throw Error(VDB_ERR_INVALID, "null pointer");
+        if (h->multi) return multi_stats(h, out);
         set_device(h->device);
         vdb_stats_t s = h->last;
+        s.ndevices = 1;
         s.ntotal = h->N;
         s.dim = h->dim;
         s.metric = h->metric;
@@ -884,6 +957,7 @@ int vdb_debug_fetch_stamps(vdb_handle hh, unsigned long long *out_host, int64_t 
     return guarded([&] {
         auto *h = check(hh);
         if (!out_host || !nwords) throw Error(VDB_ERR_INVALID, "null pointer");
+        if (h->multi) multi_unsupported("vdb_debug_fetch_stamps");
         set_device(h->device);
         const int64_t n = std::min<int64_t>((int64_t)h->dbg_words, max_words);
         *nwords = n;
@@ -898,6 +972,7 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
     return guarded([&] {
         auto *h = check(hh);
         if (!key) throw Error(VDB_ERR_INVALID, "null option name");
+        if (h->multi) return multi_set_option(h, key, value);
         const std::string k(key);
         graph_reset(h);                        // (a captured search embodies the options it was captured under)
         if (k == "graph") {
@@ -992,3 +1067,4 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
 }  // extern "C"
 
 #include "debug_ivf.inc"
+#include "multi.inc"

@@ -33,6 +33,7 @@ class Stats(Structure):
         ("scan_dtype", c_int32), ("has_i8_copy", c_int32), ("last_rows_scanned", c_int64),
         ("upload_blocks", c_int64),
         ("graph_replays", c_int64),
+        ("ndevices", c_int32), ("reserved0", c_int32),
     ]
 
     def as_dict(self):
@@ -47,6 +48,7 @@ SIGNATURES = {
     "vdb_last_error": (c_char_p, []),
     "vdb_device_count": (c_int, [POINTER(c_int)]),
     "vdb_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "vdb_create_multi": (c_int, [c_int, c_int, POINTER(c_int), c_int, POINTER(c_void_p)]),
     "vdb_destroy": (c_int, [c_void_p]),
     "vdb_reset": (c_int, [c_void_p]),
     "vdb_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
@@ -125,7 +127,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vdb_abi_version() != 3:
+        if lib.vdb_abi_version() != 4:
             raise ImportError("libvdbhip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -149,6 +151,25 @@ def check(status: int, *, build_time: bool = False) -> None:
     if status == VDB_ERR_NOMEM:
         raise MemoryError(msg)
     raise VdbError(msg)
+
+
+def create_handle(dim: int, metric: int, device) -> c_void_p:
+    """`device`: one GPU ordinal -> vdb_create; a sequence of ordinals -> vdb_create_multi (ONE index row-sharded over those
+    GPUs inside this process; an ordinal may repeat).  A sequence of length one is the single-device index."""
+    h = c_void_p()
+    lib = load()
+    if isinstance(device, (list, tuple, np.ndarray)):
+        devs = [int(d) for d in device]
+        if not devs:
+            raise ValueError("empty device list")
+        if len(devs) == 1:
+            check(lib.vdb_create(int(dim), int(metric), devs[0], ctypes.byref(h)), build_time=True)
+        else:
+            arr = (c_int * len(devs))(*devs)
+            check(lib.vdb_create_multi(int(dim), int(metric), arr, len(devs), ctypes.byref(h)), build_time=True)
+    else:
+        check(lib.vdb_create(int(dim), int(metric), int(device), ctypes.byref(h)), build_time=True)
+    return h
 
 
 def device_count() -> int:

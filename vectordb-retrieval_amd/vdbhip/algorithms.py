@@ -30,11 +30,19 @@ def _safe_normalize(matrix: np.ndarray) -> np.ndarray:
     return np.divide(matrix, norms, out=np.zeros_like(matrix), where=norms > 0)
 
 
-def _resolve_device(device: Optional[int], device_ids) -> int:
+def _resolve_device(device, device_ids):
+    """GPU(s) of an index: `device` (an ordinal, or a list of them) wins over `device_ids`; more than one ordinal means ONE
+    index row-sharded over those GPUs inside this process (vdb_create_multi) -- the reference's harness is a single process
+    (experiment_runner.py:329-331, 428-434), so this is how a YAML entry `{type: HipExactSearch, device_ids: [0, .., 7]}`
+    reaches eight MI355X.  Returns an int or a list of ints."""
+    from .index import normalize_devices
+
     if device is not None:
-        return int(device)
-    if device_ids:
-        return int(device_ids[0])
+        return normalize_devices(device)
+    if device_ids is not None and not isinstance(device_ids, (int, np.integer)) and len(device_ids) > 0:
+        return normalize_devices(list(device_ids))
+    if isinstance(device_ids, (int, np.integer)):
+        return int(device_ids)
     import os
 
     return int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("VDBHIP_DEVICE_FROM_RANK") else 0
@@ -62,11 +70,14 @@ def apply_engine_options(index, params: dict) -> None:
 
 
 class HipExactSearch(BaseAlgorithm):
-    """Exact k-NN on one MI355X; same constructor and results as ExactSearch (faiss.IndexFlat)."""
+    """Exact k-NN on one MI355X -- or, with `device_ids: [..]` of several, on ONE index row-sharded over them in this
+    process; same constructor and results as ExactSearch (faiss.IndexFlat)."""
 
-    def __init__(self, name: str, dimension: int, metric: str = "l2", device: Optional[int] = None,
+    def __init__(self, name: str, dimension: int, metric: str = "l2", device=None,
                  device_ids=None, **kwargs: Any) -> None:
         super().__init__(name, dimension, **kwargs)
+        if device_ids is not None:
+            self.config["device_ids"] = list(device_ids) if not isinstance(device_ids, (int, np.integer)) else int(device_ids)
         # exact_search.py:23 -- 'l2' -> METRIC_L2, anything else -> METRIC_INNER_PRODUCT (no normalisation)
         self.metric = "l2" if metric == "l2" else "ip"
         self.device = _resolve_device(device, device_ids)

@@ -16,18 +16,37 @@ from . import _ffi
 _METRICS = {"l2": _ffi.METRIC_L2, "ip": _ffi.METRIC_IP}
 
 
-class FlatIndex:
-    """Device-resident brute-force index on one MI355X (replaces faiss.IndexFlat(d, metric))."""
+def normalize_devices(device):
+    """int -> int; a sequence of GPU ordinals -> list (length one -> its only member)."""
+    if isinstance(device, (list, tuple, np.ndarray)):
+        devs = [int(d) for d in device]
+        if not devs:
+            raise ValueError("empty device list")
+        return devs[0] if len(devs) == 1 else devs
+    return int(device)
 
-    def __init__(self, dim: int, metric: str = "l2", device: int = 0):
+
+class FlatIndex:
+    """Device-resident brute-force index (replaces faiss.IndexFlat(d, metric)).  `device`: one GPU ordinal, or a list of
+    them -- ONE index row-sharded over those MI355X inside this process (vdb_create_multi): same calls, same results."""
+
+    def __init__(self, dim: int, metric: str = "l2", device=0):
         if metric not in _METRICS:
             raise ValueError(f"metric must be 'l2' or 'ip', got {metric!r}")
-        self.dim, self.metric, self.device = int(dim), metric, int(device)
+        self.dim, self.metric, self.device = int(dim), metric, normalize_devices(device)
         self._lib = _ffi.load()
-        h = ctypes.c_void_p()
-        _ffi.check(self._lib.vdb_create(self.dim, _METRICS[metric], self.device, ctypes.byref(h)), build_time=True)
-        self._h = h
+        self._h = _ffi.create_handle(self.dim, _METRICS[metric], self.device)
         self.ntotal = 0
+
+    @property
+    def devices(self):
+        return list(self.device) if isinstance(self.device, list) else [self.device]
+
+    def _sync_ntotal(self) -> None:
+        """The row count is the library's: an add may have replaced rows instead of appending (e.g. after a failed add)."""
+        s = _ffi.Stats()
+        _ffi.check(self._lib.vdb_stats(self._handle(), ctypes.byref(s)))
+        self.ntotal = int(s.ntotal)
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self) -> None:
@@ -53,18 +72,22 @@ class FlatIndex:
         x = _ffi.as_f32_c(vectors)
         if x.ndim != 2 or x.shape[1] != self.dim:
             raise ValueError(f"expected (n, {self.dim}) vectors, got {x.shape}")
-        _ffi.check(self._lib.vdb_add(self._handle(), _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
-        self.ntotal += int(x.shape[0])
+        try:
+            _ffi.check(self._lib.vdb_add(self._handle(), _ffi.ptr(x), x.shape[0], int(id_base)), build_time=True)
+        finally:
+            self._sync_ntotal()
 
     def add_device(self, dev_ptr: int, n: int, id_base: int = 0, stream: int = 0) -> None:
-        _ffi.check(self._lib.vdb_add_device(self._handle(), dev_ptr, int(n), int(id_base), stream or None),
-                   build_time=True)
-        self.ntotal += int(n)
+        try:
+            _ffi.check(self._lib.vdb_add_device(self._handle(), dev_ptr, int(n), int(id_base), stream or None),
+                       build_time=True)
+        finally:
+            self._sync_ntotal()
 
     def reset(self) -> None:
         """Drop every row (faiss.Index.reset)."""
         _ffi.check(self._lib.vdb_reset(self._handle()), build_time=True)
-        self.ntotal = 0
+        self._sync_ntotal()
 
     # -- search -------------------------------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:

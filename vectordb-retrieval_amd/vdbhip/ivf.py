@@ -38,15 +38,16 @@ def parse_ivf_key(key: str) -> int:
 class IVFFlatIndex:
     """Device-resident IVF-Flat index (replaces faiss.index_factory(d, "IVFn,Flat", metric))."""
 
-    def __init__(self, dim: int, nlist: int, metric: str = "l2", device: int = 0):
+    def __init__(self, dim: int, nlist: int, metric: str = "l2", device=0):
+        """`device`: one GPU ordinal or a list of them (rows of every list split over those GPUs, coarse quantizer
+        replicated: vdb_create_multi)."""
+        from .index import normalize_devices
+
         if metric not in ("l2", "ip"):
             raise ValueError(f"metric must be 'l2' or 'ip', got {metric!r}")
-        self.dim, self.nlist, self.metric, self.device = int(dim), int(nlist), metric, int(device)
+        self.dim, self.nlist, self.metric, self.device = int(dim), int(nlist), metric, normalize_devices(device)
         self._lib = _ffi.load()
-        h = ctypes.c_void_p()
-        _ffi.check(self._lib.vdb_create(self.dim, 0 if metric == "l2" else 1, self.device, ctypes.byref(h)),
-                   build_time=True)
-        self._h = h
+        self._h = _ffi.create_handle(self.dim, 0 if metric == "l2" else 1, self.device)
         self.is_trained = False
         self.ntotal = 0
         self.nprobe = 1
@@ -97,7 +98,7 @@ class IVFFlatIndex:
                 raise ValueError(f"expected {x.shape[0]} list ids, got {lor.shape}")
             _ffi.check(self._lib.vdb_ivf_add_assigned(self._h, _ffi.ptr(x), x.shape[0], int(id_base), _ffi.ptr(lor)),
                        build_time=True)
-        self.ntotal += int(x.shape[0])
+        self.ntotal = int(self.stats()["ntotal"])      # (the library's count: an add may replace instead of append)
 
     def reset(self) -> None:
         """Drop every row; the centroids stay (faiss.IndexIVF.reset)."""

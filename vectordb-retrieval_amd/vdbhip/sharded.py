@@ -25,6 +25,41 @@ from . import _ffi
 from .plugin_api import BaseAlgorithm, Metadata, SearchResult, register_algorithm
 
 
+def ensure_process_group(backend: Optional[str] = None, device: Optional[int] = None) -> Tuple[int, int]:
+    """(rank, world) of the torch.distributed job; initialises the default group from the launcher's environment when the
+    launcher started more than one rank and nobody has done it yet; raises RuntimeError when WORLD_SIZE > 1 is announced but
+    there is neither a group nor the rendezvous variables to make one.  Never world = 1 by accident."""
+    import os
+
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    try:
+        env_world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+    except ValueError:
+        env_world = 1
+    if env_world <= 1:
+        return 0, 1
+    missing = [v for v in ("RANK", "MASTER_ADDR", "MASTER_PORT") if not os.environ.get(v)]
+    if missing or not dist.is_available():
+        raise RuntimeError(
+            f"WORLD_SIZE={env_world} but no torch.distributed process group is initialised and {', '.join(missing) or 'torch.distributed'} "
+            "is missing: a row-sharded index would silently scan the whole corpus on every rank.  Launch with torchrun "
+            "(or call torch.distributed.init_process_group first), or use device_ids=[...] of HipExactSearch for the "
+            "single-process multi-GPU index.")
+    backend = backend or os.environ.get("VDBHIP_DIST_BACKEND") or "nccl"
+    kwargs = {}
+    if backend == "nccl":
+        import torch
+
+        local = int(device if device is not None else os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend=backend, **kwargs)
+    return dist.get_rank(), dist.get_world_size()
+
+
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of `rank`: [rank*ceil(n/world), min(n, (rank+1)*ceil(n/world)))."""
     per = -(-n // world) if world > 0 else n
@@ -110,11 +145,12 @@ class HipShardedExactSearch(BaseAlgorithm):
         self.ntotal = 0
 
     def _dist(self):
-        import torch.distributed as dist
-
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-        return 0, 1
+        """(rank, world) of the job this process belongs to.  A launcher that started several ranks (WORLD_SIZE > 1 in the
+        environment) but no process group is NOT served as world = 1 -- every rank would scan the whole corpus on its own GPU
+        and report nothing: with the launcher's rendezvous variables present (torchrun sets RANK / WORLD_SIZE / MASTER_ADDR /
+        MASTER_PORT) the group is initialised here (backend: kwarg `dist_backend`, $VDBHIP_DIST_BACKEND, default nccl = RCCL,
+        bound to this rank's GPU); without them it is an error."""
+        return ensure_process_group(self.config.get("dist_backend"), self._device)
 
     def build_index(self, vectors: np.ndarray, metadata: Metadata = None) -> None:
         self.rank, self.world = self._dist()
