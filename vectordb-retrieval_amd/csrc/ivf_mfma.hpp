@@ -432,6 +432,7 @@ struct IvfSelectArgs {
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
     int vals_entries;             // LDS entries per wave for the bin minima: max_entries when k > 64, else 0 (see the kernel)
     int probe_cap;                // nprobe rounded up to 64: size of the per-probe LDS arrays
+    int act_cap;                  // active bins (first minimum <= tau1 + 2 eps) a wave lists in LDS: cand_cap + rescan_cap
     int bins_per_span, bin_rows;  // level-1 bins of a panel span and rows per bin: bin b of a span covers its local rows
                                   // [b bin_rows, (b + 1) bin_rows).  Entry e of a probed list:
     int run_groups;               //   0 (K-loop scan): [span][bin], e = span * bins_per_span + bin
@@ -448,6 +449,11 @@ struct IvfSelectArgs {
 // copy the bin minima into LDS with independent, per-probe-contiguous loads.  Phase 3: bitwise bisection for
 // the k-th smallest.  Phase 4: entries <= That become candidate rows or bins to re-scan.
 constexpr int kIvfMaxProbes = 512;
+// 32-bit words of LDS per wave: vals[vals_entries] | p_off[probe_cap + 32] | p_base lo / hi [2 probe_cap] | p_list[probe_cap]
+// (+ 32 spare) | act[act_cap] | vals2[act_cap * nm]
+__host__ __device__ inline size_t ivf_select_lds_words(int vals_entries, int probe_cap, int act_cap, int nm) {
+    return (size_t)vals_entries + 4 * (size_t)probe_cap + 64 + (size_t)act_cap * (1 + nm);
+}
 
 __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 2 waves per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char ivf_smem[];
@@ -460,12 +466,14 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
     // (vals only for k > 64, whose threshold needs every bin minimum in LDS: a.vals_entries = max_entries, else 0 -- without
     //  it a wave needs ~2 KB instead of ~18 KB and eight times as many queries are in flight per CU; the second pass then
     //  re-reads the minima, L2-resident by now)
-    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * (a.vals_entries + 4 * a.probe_cap + 64);
+    unsigned *vals = reinterpret_cast<unsigned *>(ivf_smem) + (size_t)wave * ivf_select_lds_words(a.vals_entries, a.probe_cap, a.act_cap, a.nm);
     int *p_off = reinterpret_cast<int *>(vals + a.vals_entries);
     const bool keep = a.vals_entries > 0;
     unsigned *p_base_lo = reinterpret_cast<unsigned *>(p_off + a.probe_cap + 32);
     unsigned *p_base_hi = p_base_lo + a.probe_cap;
     int *p_list = reinterpret_cast<int *>(p_base_hi + a.probe_cap);
+    unsigned *act = reinterpret_cast<unsigned *>(p_list + a.probe_cap);       // [act_cap] active bins: entry | probe << 16
+    unsigned *vals2 = act + a.act_cap;                                          // [act_cap][nm] their minima (sortable keys)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool fb = a.plan->overflow || a.info->force_fallback || a.nprobe > kIvfMaxProbes;
     int E = 0;
@@ -565,50 +573,107 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
             }
         }
         const int i8_mode = a.info->i8_mode;                 // (read ONCE: in the loop below every use would be a fresh global load)
-        const float that = select_threshold(unsortable_f32(ans), a.eps[q], i8_mode);
+        const float epsq = a.eps[q];
+        const float that1 = select_threshold(unsortable_f32(ans), epsq, i8_mode);
         const int grows = group_rows_of(i8_mode);            // rows per candidate group (4, or 8 on the int8 scan)
-        if (!(that < 0.9e38f)) fb = true;
+        if (!(that1 < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
+        // ---- the ACTIVE bins (first minimum <= tau1 + 2 eps), compacted into LDS: (entry, probe) packed into one word ----
+        // Everything below works on this short list (typically k .. 2k bins of the hundreds or thousands a query meets)
+        // instead of running the whole emit logic over every entry.
+        int nact = 0;
         pcur = lane < E ? probe_of(lane) : 0;
         for (int e4 = 0; e4 < E && !fb; e4 += 256) {
-          float m1v[4];
-          int pv[4];
+            float m1v[4];
+            int pv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {      // the minima of four rounds of entries, requested together
-              const int e = e4 + 64 * u + lane;
-              m1v[u] = __builtin_inff();
-              pv[u] = 0;
-              if (e < E) {
-                  pv[u] = advance(e);
-                  if (keep) {
-                      m1v[u] = unsortable_f32(vals[e]);
-                  } else {
-                      const size_t base = ((size_t)p_base_hi[pv[u]] << 32) | p_base_lo[pv[u]];
-                      m1v[u] = a.bin_m[0][base + (e - p_off[pv[u]])];
-                  }
-              }
-          }
+            for (int u = 0; u < 4; ++u) {      // the minima of four rounds of entries, requested together
+                const int e = e4 + 64 * u + lane;
+                m1v[u] = __builtin_inff();
+                pv[u] = 0;
+                if (e < E) {
+                    pv[u] = advance(e);
+                    if (keep) {
+                        m1v[u] = unsortable_f32(vals[e]);
+                    } else {
+                        const size_t base = ((size_t)p_base_hi[pv[u]] << 32) | p_base_lo[pv[u]];
+                        m1v[u] = a.bin_m[0][base + (e - p_off[pv[u]])];
+                    }
+                }
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e4 + 64 * u + lane;
-            if (e4 + 64 * u >= E) break;
-            // an active bin whose j smallest quad minima are active and whose (j + 1)-th is not yields those j quads; when
-            // all nm minima kept are active (more quads may be) the whole bin is re-scanned -- as it is when a quad would
-            // run past the end of its list
-            int ncq = 0;                       // candidate quads of this lane's entry
+            for (int u = 0; u < 4; ++u) {
+                const int e = e4 + 64 * u + lane;
+                const bool on = e < E && m1v[u] <= that1;
+                const unsigned long long am = __ballot(on);
+                if (on) {
+                    const int pos = nact + __popcll(am & lt_mask);
+                    if (pos < a.act_cap) act[pos] = (unsigned)e | ((unsigned)pv[u] << 16);
+                }
+                nact += __popcll(am);
+            }
+        }
+        if (nact > a.act_cap) fb = true;       // (more active bins than candidates + re-scans the work lists can take)
+        // ---- tau2: the k-th smallest over ALL kept minima of the active bins.  Every minimum kept is the minimum of a
+        // different quad, i.e. they are scores of distinct rows: k of them <= tau2 bound the k-th neighbour as the k-th
+        // bin minimum does, but tighter -- the near neighbours of a query sit in one or two of its probed lists, several per
+        // bin, and the k-th smallest FIRST minimum then lies far beyond the k-th smallest score (msmarco-shaped leg: 36
+        // candidate quads and 1.1 re-scanned bins per query with tau1, 22 and 0.04 with tau2 at k = 20).  Values above
+        // tau1 + 2 eps cannot be among the k smallest (>= k first minima are <= tau1), so the active list holds them all.
+        float that = that1;
+        if (!fb && a.nm > 1) {
+            const int V = nact * a.nm;
+            for (int v = lane; v < V; v += 64) {             // gather: value v = (active bin v / nm, minimum v % nm)
+                const int ai = v / a.nm, j = v - ai * a.nm;
+                const unsigned w = act[ai];
+                const int e = (int)(w & 0xFFFFu), p = (int)(w >> 16);
+                const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
+                vals2[v] = sortable_u32(a.bin_m[j][base + (e - p_off[p])]);
+            }
+            unsigned t2 = 0;
+            if (a.k <= 32) {      // lanes' two smallest of their strided values (a bin's minima land on different lanes)
+                unsigned l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu;
+                for (int v = lane; v < V; v += 64) {
+                    const unsigned key = vals2[v];
+                    l1 = min(l1, max(l0, key));
+                    l0 = min(l0, key);
+                }
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned trial = t2 | ((1u << bit) - 1u);
+                    const int cnt = __popcll(__ballot(l0 <= trial)) + __popcll(__ballot(l1 <= trial));
+                    if (cnt < a.k) t2 |= (1u << bit);
+                }
+            } else {
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned trial = t2 | ((1u << bit) - 1u);
+                    int cnt = 0;
+                    for (int v = lane; v < V; v += 64) cnt += (vals2[v] <= trial) ? 1 : 0;
+                    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                    if (cnt < a.k) t2 |= (1u << bit);
+                }
+            }
+            if (t2 < ans) that = select_threshold(unsortable_f32(t2), epsq, i8_mode);
+        }
+        // ---- emit: an active bin whose j smallest quad minima are active and whose (j + 1)-th is not yields those j quads;
+        // when all nm minima kept are active (more quads may be) the whole bin is re-scanned -- as it is when a quad would run
+        // past the end of its list
+        for (int a0 = 0; a0 < nact && !fb; a0 += 64) {
+            const int ai = a0 + lane;
+            int ncq = 0;                       // candidate quads of this lane's bin
             bool resc = false;
             int row0 = 0, row1 = 0, crow[kIvfMaxMinima - 1] = {0, 0, 0, 0};
-            if (e < E) {
-                const float m1 = m1v[u];
-                if (m1 <= that) {
-                    const int p = pv[u], ei = e - p_off[p];
-                    const int l = p_list[p];
-                    const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
-                    float mv[kIvfMaxMinima];
-                    mv[0] = m1;
+            if (ai < nact) {
+                const unsigned w = act[ai];
+                const int e = (int)(w & 0xFFFFu), p = (int)(w >> 16);
+                const int ei = e - p_off[p];
+                const size_t base = ((size_t)p_base_hi[p] << 32) | p_base_lo[p];
+                float mv[kIvfMaxMinima];
 #pragma unroll
-                    for (int i = 1; i < kIvfMaxMinima; ++i) mv[i] = i < a.nm ? a.bin_m[i][base + ei] : __builtin_inff();
+                for (int i = 0; i < kIvfMaxMinima; ++i)
+                    mv[i] = i >= a.nm ? __builtin_inff() : (a.nm > 1 ? unsortable_f32(vals2[ai * a.nm + i]) : a.bin_m[i][base + ei]);
+                if (mv[0] <= that) {
+                    const int l = p_list[p];
                     int span_local, bin;
                     if (a.run_groups) {      // (an active entry is never run padding: that holds +inf)
                         const int bpg = a.bins_per_span / a.run_groups;            // bins of a span in one run
@@ -660,7 +725,6 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                 }
             }
             nres += __popcll(rm);
-          }
         }
         if (ncand > a.cand_cap || nres > a.rescan_cap) fb = true;
     }

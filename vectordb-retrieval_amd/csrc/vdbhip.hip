@@ -1,6 +1,8 @@
 // vdbhip.hip -- host side of libvdbhip.so: handle management, path selection, kernel launches,
 // and the extern "C" entry points declared in include/vdbhip.h.  gfx950 only.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -32,6 +34,24 @@ thread_local std::string g_last_error;
 // replayed while no buffer of this process has moved since its capture (graph_or_run)
 std::atomic<uint64_t> g_alloc_epoch{0};
 
+// Diagnostic allocation log ($VDBHIP_ALLOC_LOG=<file>): one line per device / pinned allocation and release of this library
+// ("A <ptr> <bytes>", "F <ptr> <bytes>", "HA"/"HF" for pinned host memory) and per hipGraph event of graph_or_run, flushed as
+// it is written -- after a GPU memory fault the faulting address is resolved against it offline (live range, freed range,
+// or not ours: profiles/r04_graph_fault_cause.txt).  Off unless the variable is set.
+FILE *alloc_log() {
+    static FILE *f = [] {
+        const char *path = getenv("VDBHIP_ALLOC_LOG");
+        return (path && *path) ? fopen(path, "a") : (FILE *)nullptr;
+    }();
+    return f;
+}
+void alloc_note(const char *what, const void *p, size_t bytes) {
+    if (FILE *f = alloc_log()) {
+        fprintf(f, "%s %p %zu\n", what, p, bytes);
+        fflush(f);
+    }
+}
+
 // growable device buffer
 struct DevBuf {
     void *p = nullptr;
@@ -47,13 +67,17 @@ struct DevBuf {
         if (bytes <= cap) return;
         if (borrowed) throw Error(VDB_ERR_INVALID, "internal: a borrowed device buffer cannot grow");
         g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
-        if (p) VDB_HIP(hipFree(p));
+        if (p) {
+            alloc_note("F", p, cap);
+            VDB_HIP(hipFree(p));
+        }
         p = nullptr;
         cap = 0;
         const size_t want = bytes + std::min<size_t>(bytes >> 3, (size_t)256 << 20);   // (growth slack: 1/8, at most 256 MiB)
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) throw Error(VDB_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
         cap = want;
+        alloc_note("A", p, cap);
     }
     // reserve that keeps the first `keep` bytes (append): old and new allocation coexist for the copy
     void grow(size_t bytes, size_t keep) {
@@ -73,13 +97,18 @@ struct DevBuf {
         }
         p = fresh;
         cap = want;
+        alloc_note("A", p, cap);
         if (old && keep) e = hipMemcpy(p, old, keep, hipMemcpyDeviceToDevice);
-        if (old) (void)hipFree(old);
+        if (old) {
+            alloc_note("F", old, old_cap);
+            (void)hipFree(old);
+        }
         if (e != hipSuccess) throw Error(VDB_ERR_HIP, std::string("device copy failed: ") + hipGetErrorString(e));
     }
     void release() {
         if (p && !borrowed) {
             g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+            alloc_note("F", p, cap);
             (void)hipFree(p);
         }
         p = nullptr;
@@ -155,6 +184,7 @@ struct vdb_index_s {
     // option "graph": a device-resident search that repeats with the same shape and buffers (a serving loop) is captured
     // into a hipGraph on its second call and replayed from the third (graph_or_run)
     int graph_mode = 0;
+    int graph_recapture_at_once = 0;         // diagnostic option of the same name: the pre-round-3 ordering (see graph_or_run)
     struct GraphKey {
         const void *q = nullptr, *o1 = nullptr, *o2 = nullptr;
         int64_t nq = 0;
@@ -332,13 +362,18 @@ void upload_rows(vdb_index_s *h, float *dst, int D4, const float *src, int64_t n
     const size_t need = (size_t)std::min<int64_t>(rows_per_block, n) * row_bytes;
     if (h->pin_bytes < need) {
         for (int i = 0; i < 2; ++i) {
-            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            if (h->pin[i]) {
+                alloc_note("HF", h->pin[i], h->pin_bytes);
+                (void)hipHostFree(h->pin[i]);
+            }
             h->pin[i] = nullptr;
         }
         h->pin_bytes = 0;
         if (hipHostMalloc(&h->pin[0], need, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc(&h->pin[1], need, hipHostMallocDefault) == hipSuccess) {
             h->pin_bytes = need;
+            alloc_note("HA", h->pin[0], need);
+            alloc_note("HA", h->pin[1], need);
         } else {                         // no pinned memory to be had: one pageable copy (the HIP runtime stages it itself)
             for (int i = 0; i < 2; ++i) {
                 if (h->pin[i]) (void)hipHostFree(h->pin[i]);
@@ -651,7 +686,10 @@ int vdb_destroy(vdb_handle h) {
         if (h->coarse) (void)vdb_destroy(h->coarse);
         h->ws.release();
         for (int i = 0; i < 2; ++i) {
-            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            if (h->pin[i]) {
+                alloc_note("HF", h->pin[i], h->pin_bytes);
+                (void)hipHostFree(h->pin[i]);
+            }
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
         }
         for (auto e : h->ev_scan) (void)hipEventDestroy(e);
@@ -978,6 +1016,8 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         if (k == "graph") {
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "graph must be 0 or 1");
             h->graph_mode = (int)value;
+        } else if (k == "graph_recapture_at_once") {   // diagnostic: destroy a stale exec and capture its successor in ONE call
+            h->graph_recapture_at_once = value != 0;
         } else if (k == "force_path") {
             if (value != 0 && value != 1 && value != 2 && value != 3)
                 throw Error(VDB_ERR_INVALID, "force_path must be 0, 1, 2 or 3");
