@@ -218,7 +218,11 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       at most 4096 queries on a non-null stream that repeats with the same buffers, shape and stream
  *                       (a serving loop) is captured into a hipGraph on its second occurrence and replayed afterwards;
  *                       any vdb_set_option / add / train drops the graph; the caller keeps the buffers alive and
- *                       rewrites the queries in place
+ *                       rewrites the queries in place.  (The call that drops a stale graph always runs eagerly: on ROCm 7.x an
+ *                       executable graph instantiated right behind the destruction of its predecessor faults on its second
+ *                       replay -- a runtime defect in graph packet capture, profiles/r04_graph_fault_cause.txt.)
+ *     "graph_recapture_at_once"  diagnostic, 0 (default) | 1: the pre-round-3 ordering, for re-checking that defect
+ *                       ($VDBHIP_ALLOC_LOG=<file> logs every allocation / graph event for scripts/graph_fault_analyze.py)
  *   tuning knobs (scripts/sweep_*.py)
  *     "i8_variant"      0..7: tile / stage / wave shapes of the flat int8 scan (6 / 7: variant 3 with a pacing barrier
  *                       per 1 / 2 tiles)
