@@ -22,14 +22,20 @@ N = 1   headline = BASELINE.json configs[1]: SIFT1M-shaped corpus (1 000 000 x 1
           also.serving      1 / 64-query batches: latency + the HBM roofline of the scan, on the Infinity-Cache-resident
                             1M x 128 copy (labelled so) and on a 4M x 128 copy (also.serving.bytes4m, 512 MB > 256 MiB: a true HBM number)
           also["marco12.5m"] configs[4] per-GPU shard, the N = 1 point of the N > 1 series
-N > 1   default workload = BASELINE.json configs[4] per-GPU shard: 12.5M x 768 inner product, rows generated on
-        device (block seeds by GLOBAL block number: the corpus does not depend on N).  One process per GPU
+N > 1   the SAME headline workload, weak scaling: every rank holds its own 1M x 128 sift1m shard (rows seeded by rank, ids
+        offset by rank x 1M), the same 10 000 queries; `value` = N x queries / time -- "query x shard scans per second" -- so the
+        driver's N = 1 / 2 / 4 / 8 series is ONE workload and its N = 1 point is the BENCH line.  One process per GPU
         (torch.distributed, backend nccl = RCCL); launched by the driver's torchrun line, or by this script itself.
-        --scaling weak (default): every rank holds 12.5M rows (100M at N = 8); `value` = (query x shard) scans / s.
-        --scaling strong: the 12.5M-row corpus is SPLIT over the N ranks (same rows, same queries, same result for
-        every N: `result_checksum`); `value` = queries / s against the whole corpus.
-        Every rank scans ITS shard for the SAME 10 000-query batch; partial (key64, id) lists are all-gathered and
-        merged on every rank; `exchange_ms` times that all-gather + merge alone.
+        Every rank scans ITS shard for the SAME query batch (vdb_search_partial_device); the packed partial (key64, id) lists
+        are exchanged with ONE all-gather and merged on every rank; `exchange_ms` times that all-gather + merge alone.
+        also["marco12.5m"] carries BASELINE.json configs[4] (12.5M x 768 inner product per GPU, rows generated on device,
+        block seeds by GLOBAL block number: the corpus does not depend on N) with BOTH figures:
+          weak    every rank holds 12.5M rows (100M at N = 8); value = N x queries / time
+          strong  the 12.5M-row corpus is SPLIT over the N ranks (same rows, same queries, same result for every N:
+                  `result_checksum`); value = queries / s against the whole corpus
+        (--workload marco12.5m / --scaling strong put one of them in the headline instead.)
+        Rehearsal on a one-GPU box: VDBHIP_BENCH_SHARED_GPU=1 (every rank on GPU 0, gloo collectives staged through the
+        host): tests/test_gpu_bench_ranks.py runs this file's N = 2 code that way.
 
 Output: ONE JSON line on rank 0.
 """
@@ -63,6 +69,7 @@ WORKLOADS = {
     # BASELINE configs[4] per-GPU shard (100M x 768 over 8 GPUs): rows generated ON DEVICE in fixed 500k-row
     # blocks seeded by the global block number, so the data do not depend on the number of ranks
     "marco12.5m": (12_500_000, 768, 10_000, 10, "ip", "device_gaussian"),
+    "marco1m": (1_000_000, 768, 2_000, 10, "ip", "device_gaussian"),       # the same shape in small: N > 1 rehearsals (tests)
     "gauss50m": (50_000_000, 128, 10_000, 10, "l2", "device_gaussian"),     # capacity check of the flat D <= 128 path
     "bytes4m": (4_000_000, 128, 64, 10, "l2", "device_bytes"),              # serving leg: scan copy > Infinity Cache
     "smoke": (10_000, 128, 100, 10, "l2", "random_reference"),
@@ -126,7 +133,7 @@ def device_rows(n: int, d: int, rank: int, dev):
     return device_rows_range(base, base + n, d, dev)
 
 
-def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32, dist=None, world: int = 1) -> float:
+def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int = 32, ranks=None) -> float:
     """Recall of the first `sample` queries against a float64 torch scan of the device-resident corpus (used for
     workloads too large to hand to the CPU oracle).  With world > 1 every rank scans ITS shard, the per-shard exact
     top-k (scores + global ids) are all-gathered and merged, and the merged list is what the result is compared with
@@ -146,11 +153,8 @@ def device_check(X_t, q_t, I_t, k: int, metric: str, id_base: int, sample: int =
             cv, ci = torch.cat([best_v, v], 1), torch.cat([best_i, i], 1)
             best_v, sel = torch.topk(cv, k, dim=1)
             best_i = torch.gather(ci, 1, sel)
-    if dist is not None and world > 1:
-        vs = [torch.empty_like(best_v) for _ in range(world)]
-        ids = [torch.empty_like(best_i) for _ in range(world)]
-        dist.all_gather(vs, best_v.contiguous())
-        dist.all_gather(ids, best_i.contiguous())
+    if ranks is not None and ranks.world > 1:
+        vs, ids = ranks.all_gather_list(best_v), ranks.all_gather_list(best_i)
         cv, ci = torch.cat(vs, 1), torch.cat(ids, 1)
         best_v, sel = torch.topk(cv, k, dim=1)
         best_i = torch.gather(ci, 1, sel)
@@ -408,10 +412,11 @@ def ivf_leg(vdbhip, torch, dev, local_rank, stream, steps, warmup, nprobes, name
         ids = I_t.cpu().numpy()
         rows_probed = float(st.get("last_rows_scanned", 0)) or nq * p / float(nlist) * n
         roof = roofline_of(st, nq, n, d, name, ivf_rows_probed=rows_probed, traffic_key=f"{name}_nprobe{p}")
-        roof["hbm_equiv"] = {"bound": "hbm", "achieved": round(4.0 * d * rows_probed / (roof["kernel_ms"] * 1e-3) / 1e9, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "note": "SURVEY 8(d): 4*D bytes x (query, row) pairs / scan time -- what a per-query list "
-                                     "scan would have to stream; the list-major scan reads a list once per query group"}
+        roof["bytes_avoided"] = {"per_query_scan_bytes": 4.0 * d * rows_probed,
+                                 "note": "SURVEY 8(d)'s per-query IVF figure (4*D bytes x (query, row) pairs): what a query-major "
+                                         "list scan would stream per batch.  NOT a roofline: the list-major scan reads every "
+                                         "probed list once per group of query slots, so it is MFMA- (nprobe 32 / 128) or "
+                                         "launch-bound (nprobe 8), not bound by these bytes"}
         point = {"value": round(nq * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
                  "dtype": scan_dtype_name(st), **host, "roofline": roof,
                  "recall@10_vs_exact": round(recall_vs(exact_ids, ids, min(k, 10)), 6),
@@ -568,17 +573,36 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None, traffic_key=None):
     if traffic and scan_ms > 0:     # what the recorded traffic amounts to at THIS run's kernel time (fabric-side bytes: HBM + Infinity Cache)
         rate = traffic / (scan_ms * 1e-3) / 1e12
         memory_side = {"traffic_tb_s": round(rate, 2), "traffic_over_hbm_peak": round(rate / (HBM_PEAK_GBS / 1000.0), 3)}
+    # the three stages of a search from the library's HIP events (vdb_stats: prep | dominant kernel | tail): the roofline names
+    # the scan, and says so when another stage is the longest (the msmarco-shaped leg's tail outlasted its scan)
+    pipeline_ms = float(st["last_total_ms"])
+    stages = {"prep": round(float(st.get("last_prep_ms", 0.0)), 4), "scan": round(scan_ms, 4),
+              "tail": round(float(st.get("last_tail_ms", 0.0)), 4)}
+    longest = max(stages, key=stages.get)
+    stage_names = {"prep": ("query statistics + operands" + (" + coarse quantizer search + plan" if ivf_rows_probed is not None else "")),
+                   "scan": kernel,
+                   "tail": ("ivf_select_kernel + ivf_tail_kernel" if ivf_rows_probed is not None else "select_kernel + refine_tail_kernel")
+                           + " (bin select + exact refine)"}
     return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TOP/s (int8)" if i8 else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, **memory_side,
             "traffic_source": (source + " -- a recorded PMC pass of an earlier run of this command, not measured in "
                                "this run") if source else None,
-            "kernel_ms": round(scan_ms, 4), "pipeline_ms": round(float(st["last_total_ms"]), 4),
+            "kernel_ms": round(scan_ms, 4), "pipeline_ms": round(pipeline_ms, 4),
+            "stages_ms": stages, "longest_stage": longest, "longest_stage_kernels": stage_names[longest],
+            "scan_share_of_pipeline": round(scan_ms / pipeline_ms, 4) if pipeline_ms > 0 else None,
+            "end_to_end_frac": round(flops / (pipeline_ms * 1e-3) / 1e12 / peak, 4) if pipeline_ms > 0 else None,
             "algorithmic_flops_per_launch": flops}
 
 
 def result_checksum(I_t) -> str:
     """CRC32 of the (nq, k) int64 result ids: equal across N under --scaling strong (the merge is shard-count invariant)."""
     return "%08x" % (zlib.crc32(I_t.cpu().numpy().tobytes()) & 0xFFFFFFFF)
+
+
+def shared_gpu() -> bool:
+    """Rehearsal mode ($VDBHIP_BENCH_SHARED_GPU=1): every rank uses GPU 0 and the collectives run over gloo, staged through the
+    host (RCCL refuses two ranks on one device) -- the N > 1 code of this file on a one-GPU box (tests/test_gpu_bench_ranks.py)."""
+    return os.environ.get("VDBHIP_BENCH_SHARED_GPU") == "1"
 
 
 def launch_ranks(args) -> int:
@@ -589,7 +613,7 @@ def launch_ranks(args) -> int:
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not shared_gpu():
         raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}")
     port = int(os.environ.get("MASTER_PORT", 29400 + os.getpid() % 2000))
     procs, out0 = [], ROOT / "gpurun_out" / f".bench_rank0_{os.getpid()}.out"
@@ -658,7 +682,9 @@ def main() -> int:
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
-    workload = args.workload or ("sift1m" if args.gpus == 1 else "marco12.5m")
+    # the headline workload is the SAME for every N (BASELINE.json configs[1]): sift1m, weak scaling for N > 1 -- every rank holds
+    # its own 1M x 128 shard, value = N x queries / time, so the N = 1 point of the driver's scaling series IS the BENCH line
+    workload = args.workload or "sift1m"
 
     # stdout carries exactly ONE line, the JSON result: everything native libraries print on file descriptor 1 while
     # the job runs (the pool exports NCCL_DEBUG=VERSION, so RCCL prints a five-line banner there) goes to stderr
@@ -667,7 +693,7 @@ def main() -> int:
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if shared_gpu() else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -736,7 +762,10 @@ def single_gpu_line(args, workload, vdbhip, torch, dev, local_rank, stream, cpu_
     name = {"sift1m": "SIFT1M%s, 10k-query batch, k=10" % ("" if real else "-shaped")}.get(workload, f"{workload}, k={k}")
     out = {"metric": f"QPS @ recall@10 ({name})", "value": head["value"], "unit": "queries/s", **contract,
            "ms_per_step": head["ms_per_step"], "dtype": head["dtype"], "data": data_tag,
-           "config": {"workload": head["config"] + "; inputs resident in HBM", "rows_per_gpu": n, "dim": d, "queries": nq,
+           "config": {"workload": head["config"] + "; `value` = inputs and results resident in HBM (bench contract)"
+                                  + ("; with NumPy queries in and NumPy (D, I) out per SURVEY 8(d): %.2f M QPS, first call %.2f ms"
+                                     % (head["value_host_io"] / 1e6, head["first_call_ms"]) if "value_host_io" in head else ""),
+                      "rows_per_gpu": n, "dim": d, "queries": nq,
                       "k": k, "metric": metric, "sharding": "none"},
            "value_device_resident": head["value"]}
     for key in ("value_host_io", "host_io_ms", "first_call_ms"):
@@ -816,18 +845,72 @@ def device_corpus_line(args, workload, vdbhip, torch, dev, local_rank, stream):
     return out
 
 
-def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, stream):
-    """N > 1 (or the one-rank rehearsal VDBHIP_BENCH_FORCE_SHARDED=1): row shards, ONE all-gather of packed partials, merge."""
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+class Ranks:
+    """The job's process group as bench.py uses it: RCCL (backend nccl, device tensors) on a multi-GPU node; in the shared-GPU
+    rehearsal gloo with every collective staged through the host."""
 
-        dist.init_process_group("nccl", device_id=dev)
+    def __init__(self, torch, dev, world):
+        self.torch, self.dev, self.world, self.dist = torch, dev, world, None
+        self.backend = "none"
+        if world > 1:
+            import torch.distributed as dist
+
+            self.dist = dist
+            self.backend = os.environ.get("VDBHIP_BENCH_BACKEND") or ("gloo" if shared_gpu() else "nccl")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def all_gather_packed(self, all_pack, my_pack):
+        """(2, nq, k) per rank -> (world, 2, nq, k): ONE collective."""
+        if self.world == 1:
+            all_pack.copy_(my_pack.unsqueeze(0))
+        elif self.backend == "nccl":
+            self.dist.all_gather_into_tensor(all_pack, my_pack)
+        else:
+            host = my_pack.cpu()
+            parts = [self.torch.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host)
+            all_pack.copy_(self.torch.stack(parts))
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_list(self, t):
+        """every rank's copy of the device tensor `t` (device_check)."""
+        if self.backend == "nccl":
+            out = [self.torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(out, t.contiguous())
+            return out
+        host = t.contiguous().cpu()
+        parts = [self.torch.empty_like(host) for _ in range(self.world)]
+        self.dist.all_gather(parts, host)
+        return [p.to(t.device) for p in parts]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def sharded_leg(args, workload, strong, vdbhip, torch, dev, rank, local_rank, ranks, stream, steps, warmup):
+    """One row-sharded workload over the job's ranks: every rank scans ITS shard for the same query batch
+    (vdb_search_partial_device), ONE all-gather of the packed partials, merge on every rank."""
+    world = ranks.world
     n_total, d, nq, k, metric, gen = WORKLOADS[workload]
-    strong = args.scaling == "strong"
     if strong:
         if gen != "device_gaussian":
-            raise SystemExit("--scaling strong needs a device-generated workload (marco12.5m)")
+            raise SystemExit("--scaling strong needs a device-generated workload (marco12.5m, marco1m)")
         lo, hi = n_total * rank // world, n_total * (rank + 1) // world
     else:
         lo, hi = rank * n_total, (rank + 1) * n_total      # (global row ids; host-generated shards are seeded by rank)
@@ -862,10 +945,7 @@ def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, st
         index.search_partial_device(q_t.data_ptr(), nq, k, my_pack[0].data_ptr(), my_pack[1].data_ptr(), stream)
 
     def exchange_step():
-        if world > 1:
-            dist.all_gather_into_tensor(all_pack, my_pack)
-        else:
-            all_pack.copy_(my_pack.unsqueeze(0))
+        ranks.all_gather_packed(all_pack, my_pack)
         vdbhip.merge_packed_partials_device(metric, local_rank, all_pack.data_ptr(), world, nq, k,
                                             D_t.data_ptr(), I_t.data_ptr(), stream)
 
@@ -873,43 +953,35 @@ def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, st
         local_step()
         exchange_step()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def timed(fn, reps):
-        fence()
+        ranks.fence()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        fence()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        ranks.fence()
+        return ranks.max_over_ranks(time.perf_counter() - t0)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     # untimed side measurements: this rank's shard scan without the exchange, and the exchange (all-gather + merge) alone
     shard_alone_ms = timed(local_step, 3) / 3 * 1e3
     exchange_ms = timed(exchange_step, 10) / 10 * 1e3
     index.set_option("timing", 1)      # HIP events around the scan kernel, on the search stream, per step
-    elapsed = timed(step, args.steps)
+    elapsed = timed(step, steps)
     st = index.stats()
     index.set_option("timing", 0)
 
-    ms_per_step = elapsed / args.steps * 1e3
-    qps_corpus = nq * args.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    qps_corpus = nq * steps / elapsed
     value = qps_corpus if strong else world * qps_corpus
     corpus_rows = n_total if strong else world * n_total
-    out = {
+    transport = {"nccl": "RCCL all-gather (all_gather_into_tensor, device buffers)",
+                 "none": "one rank: the all-gather is a copy"}.get(ranks.backend, f"{ranks.backend} all-gather staged through the host "
+                                                                                 f"(shared-GPU rehearsal, NOT the product transport)")
+    leg = {
         "metric": f"QPS ({workload}, k={k}" + (", strong scaling: whole-corpus queries/s)" if strong
                                               else ", weak scaling: query x shard scans/s)"),
-        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": scan_dtype_name(st), "data": "synthetic",
         "config": {"workload": f"{workload}: {n} rows x {d} dims on this GPU, {nq} queries, k={k}, {metric}; brute-force "
@@ -918,25 +990,48 @@ def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, st
                    "sharding": (f"row-sharded x{world} (strong scaling: the {n_total}-row corpus split over the ranks)"
                                 if strong else
                                 f"row-sharded x{world} (weak scaling: corpus = {world} x {n_total} rows)")
-                               + ", RCCL all-gather of packed partial top-k + merge on every rank"},
-        "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
+                               + f", {transport} of packed partial top-k + merge on every rank"},
+        "rccl_ranks": int(ranks.dist.get_world_size()) if (world > 1 and ranks.backend == "nccl") else (1 if world == 1 else 0),
+        "ranks": world, "collective_backend": ranks.backend,
         "roofline": roofline_of(st, nq, n, d, workload),
         "pipeline": pipeline_of(st, nq, build_s, float(n) * d * 4),
         "qps_whole_corpus": round(qps_corpus, 1),
         "shard_scan_alone_ms": round(shard_alone_ms, 4),
         "exchange_ms": round(exchange_ms, 4),
-        "exchange_note": f"all_gather_into_tensor of {my_pack.numel() * 8} bytes per rank + merge of {world} partial lists "
+        "exchange_note": f"all-gather of {my_pack.numel() * 8} bytes per rank + merge of {world} partial lists "
                          f"per query, timed alone (10 repetitions, max over ranks)",
         "result_checksum": result_checksum(I_t),
-        "scaling_reference": ("the N = 1 point of this workload is `also[\"%s\"]` of the `--gpus 1` line (value, "
-                              "result_checksum), or `--gpus 1 --workload %s`: the default N = 1 workload is sift1m, a "
-                              "different problem" % (workload, workload)),
     }
     if X is None:
-        out["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, lo, dist=dist,
-                                                                       world=world), 6)
-    if world > 1:
-        dist.destroy_process_group()
+        leg["recall@10_vs_float64_torch_sample"] = round(device_check(X_t, q_t, I_t, k, metric, lo, ranks=ranks), 6)
+    else:      # host-generated shard: this rank's part of the merged result against the CPU oracle on its own rows is not the
+        # merged truth; check instead that every returned id of a query sample is the exact neighbour among ALL shards
+        leg["recall@10_vs_float64_torch_sample"] = round(
+            device_check(torch.from_numpy(X).to(dev), q_t, I_t, k, metric, lo, ranks=ranks), 6)
+    index.close()
+    del X_t
+    torch.cuda.empty_cache()
+    return leg
+
+
+def sharded_line(args, workload, vdbhip, torch, dev, rank, local_rank, world, stream):
+    """N > 1 (or the one-rank rehearsal VDBHIP_BENCH_FORCE_SHARDED=1).  Headline = the SAME workload as the N = 1 line (sift1m,
+    BASELINE.json configs[1]) under weak scaling: every rank holds its own 1M x 128 shard, `value` = N x queries / time -- so
+    the driver's N = 1 / 2 / 4 / 8 series is one workload and its N = 1 point is the BENCH line.  The config-5 shard
+    (12.5M x 768 per GPU, BASELINE.json configs[4]) rides along as also["marco12.5m"] with both its weak and its strong figure
+    (N = 1 points: also["marco12.5m"] of the `--gpus 1` line)."""
+    ranks = Ranks(torch, dev, world)
+    strong = args.scaling == "strong"
+    out = sharded_leg(args, workload, strong, vdbhip, torch, dev, rank, local_rank, ranks, stream, args.steps, args.warmup)
+    out["scaling_reference"] = ("N = 1 point: the `--gpus 1` line's `value` for sift1m (the same shard, searched without the "
+                                "gather + merge); for marco12.5m `also[\"marco12.5m\"]` of that line (value, result_checksum)")
+    if workload == "sift1m" and not args.no_extras:
+        also = {}
+        for mode in ("weak", "strong"):
+            also[mode] = sharded_leg(args, "marco12.5m", mode == "strong", vdbhip, torch, dev, rank, local_rank, ranks, stream,
+                                     min(args.steps, 10), min(args.warmup, 2))
+        out["also"] = {"marco12.5m": also}
+    ranks.close()
     return out
 
 

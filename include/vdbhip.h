@@ -80,6 +80,10 @@ typedef struct vdb_stats_s {
     int64_t graph_replays;     /* searches served by launching the captured hipGraph (option "graph") since the handle was made */
     int32_t ndevices;          /* shards of the handle: 1, or the ndev of vdb_create_multi (sums / maxima over the shards above) */
     int32_t reserved0;
+    float last_prep_ms;        /* timing on: mean time from the start of the device pipeline to the start of the dominant kernel
+                                  (query statistics / operands; IVF: + coarse search, plan) ... */
+    float last_tail_ms;        /* ... and from its end to the end of the pipeline (bin select + exact refine): with last_scan_ms
+                                  the three stages of a search, so a caller can name the longest one */
 } vdb_stats_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -233,6 +237,8 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *     "ivf_bt"          0 auto | 4 (64-row bins) | 16 (the largest: one bin per half of a 256-row span)
  *     "ivf_tps"         D > 128, takes effect at the next vdb_ivf_add: 0 auto | 16 (256-row spans, 64-row bins) | 64
  *                       (1024-row spans, 256-row bins) of the p16 panel space
+ *     "ivf_group"       D > 128, 64-row bins: rows per candidate group of the list scan, 0 auto | 1 | 2 | 4 (smaller groups cost
+ *                       select instructions in the scan and save gathered rows in the exact refine)
  *     "ivf_part"        0 auto | spans (256 rows) per row part of the IVF list scan: long lists are cut into parts
  *                       scanned by one workgroup each (rounded up to a multiple of 4 bins)
  *     "select_variant"  0..2;  "spans_per_chunk", "kloop_qgroup": grid shaping of the flat scans

@@ -16,10 +16,12 @@ ap.add_argument("--nws", default="0,2,4,8")
 ap.add_argument("--option", default="ivf_nw")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--workload", default="sift1m", help="sift1m (nlist 1024) | msmarco_ivf (100 000 x 384, nlist 100, k = 20)")
+ap.add_argument("--nlist", type=int, default=0)
 args = ap.parse_args()
-X, Q, k, metric = make_data("sift1m", 0)
+X, Q, k, metric = make_data(args.workload, 0)
 dev = torch.device("cuda:0")
-idx = vdbhip.IVFFlatIndex(X.shape[1], 1024, metric, 0)
+idx = vdbhip.IVFFlatIndex(X.shape[1], args.nlist or (100 if args.workload == "msmarco_ivf" else 1024), metric, 0)
 idx.train(X)
 idx.add(X)
 q_t = torch.from_numpy(Q).to(dev)
@@ -51,4 +53,5 @@ for nprobe in [int(v) for v in args.nprobes.split(",")]:
             res[v]["total"].append(st["last_total_ms"])
     for v in nws:
         print(json.dumps({"nprobe": nprobe, args.option: v, "scan_ms_med": round(float(np.median(res[v]["scan"])), 4),
-                          "total_ms_med": round(float(np.median(res[v]["total"])), 4)}))
+                          "total_ms_med": round(float(np.median(res[v]["total"])), 4),
+                          "candidates_per_query": round(st["last_candidates"] / len(Q), 2), "rescan_bins": st["last_rescan_bins"]}))

@@ -274,28 +274,30 @@ def test_bench_recall_check_merges_the_shards_exact_lists():
     I_true = torch.topk(s, k, dim=1).indices                       # exact result over BOTH shards, global ids
 
     class Recorder:                                                # captures what a rank would contribute
+        world = 2
+
         def __init__(self):
             self.sent = []
 
-        def all_gather(self, lst, t):
+        def all_gather_list(self, t):
             self.sent.append(t.clone())
-            for x in lst:
-                x.copy_(t)
+            return [t, t]
 
     rec = Recorder()
-    bench.device_check(X[2000:], Q, I_true, k, "ip", 2000, dist=rec, world=2)
+    bench.device_check(X[2000:], Q, I_true, k, "ip", 2000, ranks=rec)
     other_v, other_i = rec.sent
 
-    class Rank0:                                                   # rank 0's view of a two-rank all_gather
+    class Rank0:                                                   # rank 0's view of a two-rank all-gather
+        world = 2
+
         def __init__(self):
             self.calls = 0
 
-        def all_gather(self, lst, t):
-            lst[0].copy_(t)
-            lst[1].copy_(other_v if self.calls == 0 else other_i)
+        def all_gather_list(self, t):
             self.calls += 1
+            return [t, other_v if self.calls == 1 else other_i]
 
-    assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0, dist=Rank0(), world=2) == 1.0
+    assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0, ranks=Rank0()) == 1.0
     assert bench.device_check(X[:2000], Q, I_true, k, "ip", 0) < 0.9      # (one shard alone cannot explain the merged result)
 
 

@@ -54,12 +54,70 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const half8 *__restri
     }
 }
 
+// The same scores for D > 128 (IVF coarse quantizers over 384 / 768-dim embeddings: a few hundred centroids): the k-step loop
+// is a run-time loop, four k-steps of operand loads in flight per wave (panels and query fragments come from L2 -- the
+// centroid panels are a few hundred KiB).  Tiles that hold padding rows only store the padding score without touching the
+// operands (100 centroids fill 7 of the 16 tiles of their 512-row span).  Replaces the float64 exhaustive kernel there:
+// 192 us -> ~15 us per 10 000 queries x 100 centroids x 384 dims (profiles/r04_msmarco_ivf_breakdown.txt).
+__global__ __launch_bounds__(256) void dense_scores_kloop_kernel(const half8 *__restrict__ panels, const float *__restrict__ bias,
+                                                                 const half8 *__restrict__ qpanels,
+                                                                 const QueryBatchInfo *__restrict__ info, int64_t ntiles,
+                                                                 int64_t Npad, int64_t N, int ksteps, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int64_t qt = blockIdx.y;                          // 64-query tile
+    const float cs = info->cs;
+    const int64_t span = tile / kTilesPerSpan;
+    const int t = (int)(tile - span * kTilesPerSpan);
+    const int64_t row0 = span * kSpanRows + (int64_t)h * kBinRows + t * 16;
+    float16v acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 c = *reinterpret_cast<const float4 *>(bias + row0 + 4 * g);
+        acc0[4 * g + 0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
+        acc0[4 * g + 1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
+        acc0[4 * g + 2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
+        acc0[4 * g + 3] = (c.w >= 0.9e38f) ? kPadBias : c.w * cs;
+    }
+    acc1 = acc0;
+    const bool any_row = span * kSpanRows + t * 16 < N;     // (the first row of the tile's lower half: both halves past N otherwise)
+    if (any_row) {
+        const half8 *pa = panels + (size_t)tile * ksteps * 64 + lane;
+        const half8 *pb0 = qpanels + (size_t)(qt * 2 + 0) * ksteps * 64 + lane;
+        const half8 *pb1 = qpanels + (size_t)(qt * 2 + 1) * ksteps * 64 + lane;
+        for (int ks = 0; ks < ksteps; ks += 4) {            // (ksteps is a multiple of 4 for D > 128)
+            half8 af[4], bf0[4], bf1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                af[u] = pa[(size_t)(ks + u) * 64];
+                bf0[u] = pb0[(size_t)(ks + u) * 64];
+                bf1[u] = pb1[(size_t)(ks + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf1[u], acc1, 0, 0, 0);
+            }
+        }
+    }
+    float4 *o0 = reinterpret_cast<float4 *>(out + (size_t)(qt * 64 + (lane & 31)) * Npad + row0);
+    float4 *o1 = reinterpret_cast<float4 *>(out + (size_t)(qt * 64 + 32 + (lane & 31)) * Npad + row0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o0[g] = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+        o1[g] = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+    }
+}
+
 struct DenseSelectArgs {
     RefineCommon c;
     const float *scores;       // [Qpad][Npad]
     const float *eps;          // [nq]
     const QueryBatchInfo *info;
     int64_t nq, Npad;
+    int64_t ncols;             // register kernel: score columns it reads = the index's rows rounded up to 64 (0 = Npad; the
+                               // columns beyond hold padding scores: 100 centroids fill 2 of the 8 column groups of their span)
     int cand_cap;              // candidates kept in LDS per query
     int32_t *fallback;         // [nq]
     int32_t *fb_list;
@@ -165,7 +223,7 @@ __global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_
     if (q >= a.nq) return;
     int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * 2 * a.cand_cap;      // rows | their approximate keys
     unsigned *ckeys = reinterpret_cast<unsigned *>(cands + a.cand_cap);
-    const int n = (int)a.Npad, k = a.c.k;
+    const int n = (int)(a.ncols > 0 ? a.ncols : a.Npad), k = a.c.k;
     const float *src = a.scores + (size_t)q * a.Npad;
     unsigned v[VPL];
     float sv[VPL];                                  // (all loads in flight before the first use: see select_kernel, scan.hpp)

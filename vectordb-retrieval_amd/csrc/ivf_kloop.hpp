@@ -45,8 +45,13 @@ struct IvfKloopArgs {
 
 constexpr int kIvfKloopGroup = 512;     // query slots per work item
 
-template <int TPS, int BS>
+// GROUP = rows per candidate group (the unit a packed 6-bit id names and the refine re-scores): 4 = the quad of a tile (any TPS),
+// 2 / 1 = pairs / single rows (TPS = 16 only: 32 / 64 ids per 64-row bin).  Smaller groups cost select instructions here
+// (one sorted insertion per group: 9 -> 14 -> 24 vector ops per quad of scores) and save gathered rows in the refine, which
+// is bound by exactly that gather: 90 -> 47 -> 26 rows of 1.5 KB per query on the msmarco-shaped leg.
+template <int TPS, int BS, int GROUP = 4>
 __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) {
+    static_assert(GROUP == 4 || ((GROUP == 2 || GROUP == 1) && TPS == 16), "pairs / rows need the 64-row bins of TPS = 16");
     constexpr int NWAVES = 8, RING = 2 * BS, HT = 8, CB = 4;
     constexpr int PPS = TPS / HT;                            // passes per span
     constexpr int SPANROWS = TPS * 16, BINROWS = TPS * 4;
@@ -194,12 +199,22 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
             const unsigned id = (unsigned)(slice * HT + t);  // tile number inside the span = quad number inside the bin
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
-                                          fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
-                const float v = pack_score(qm, idmask, id);
+                auto insert = [&](float v) {
 #pragma unroll
-                for (int i = NM - 1; i > 0; --i) m[i][cb] = __builtin_amdgcn_fmed3f(m[i - 1][cb], m[i][cb], v);
-                m[0][cb] = fast_min(m[0][cb], v, NEG_INF);
+                    for (int i = NM - 1; i > 0; --i) m[i][cb] = __builtin_amdgcn_fmed3f(m[i - 1][cb], m[i][cb], v);
+                    m[0][cb] = fast_min(m[0][cb], v, NEG_INF);
+                };
+                if (GROUP == 4) {
+                    const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
+                                              fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
+                    insert(pack_score(qm, idmask, id));
+                } else if (GROUP == 2) {
+                    insert(pack_score(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF), idmask, 2 * id));
+                    insert(pack_score(fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), idmask, 2 * id + 1));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) insert(pack_score(acc[t][cb][i], idmask, 4 * id + i));
+                }
             }
         }
         if (slice == PPS - 1) {                              // the four bins (span, g) are complete: [item][slot][bin]

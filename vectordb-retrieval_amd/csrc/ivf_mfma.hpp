@@ -404,16 +404,27 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(IvfPrepArgs a) {
         query_eps_body((int64_t)blockIdx.x * 256 + threadIdx.x, e);
         return;
     }
-    const int64_t i = (int64_t)(blockIdx.x - a.n_eps_blocks) * 256 + threadIdx.x;
-    if (i >= a.nq * a.Dpad) return;
-    const int64_t q = i / a.Dpad;
-    const int d = (int)(i - q * a.Dpad);
+    // query rows: 8 consecutive dims per thread (one 16-byte fp16 store / one 8-byte int8 store; Dpad is a multiple of 32)
+    const int64_t i8 = ((int64_t)(blockIdx.x - a.n_eps_blocks) * 256 + threadIdx.x) * 8;
+    if (i8 >= a.nq * a.Dpad) return;
+    const int64_t q = i8 / a.Dpad;
+    const int d0 = (int)(i8 - q * a.Dpad);
     const int mode = info->i8_mode;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (d0 + j < a.D) ? a.Q[(size_t)q * a.D + d0 + j] : 0.f;
     if (mode && a.q8) {
         const int cq = (mode & 3) == 1 ? 127 : -1;
-        a.q8[i] = (signed char)(d < a.D ? cq - (int)a.Q[(size_t)q * a.D + d] : 0);
+        union { signed char c[8]; int2 w; } o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.c[j] = (signed char)(d0 + j < a.D ? cq - (int)v[j] : 0);
+        *reinterpret_cast<int2 *>(a.q8 + i8) = o.w;
     } else {
-        a.qrows[i] = (_Float16)(d < a.D ? a.Q[(size_t)q * a.D + d] * info->bscale : 0.f);
+        const float bs = info->bscale;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)(v[j] * bs);
+        *reinterpret_cast<half8 *>(a.qrows + i8) = o;
     }
 }
 
@@ -432,6 +443,7 @@ struct IvfSelectArgs {
     int nprobe, group, k, cand_cap, rescan_cap, max_entries;
     int vals_entries;             // LDS entries per wave for the bin minima: max_entries when k > 64, else 0 (see the kernel)
     int probe_cap;                // nprobe rounded up to 64: size of the per-probe LDS arrays
+    int group_rows;               // rows per candidate group: 0 = by the scan's arithmetic (4, or 8 on the int8 scan); 1 / 2 / 4 given
     int act_cap;                  // active bins (first minimum <= tau1 + 2 eps) a wave lists in LDS: cand_cap + rescan_cap
     int bins_per_span, bin_rows;  // level-1 bins of a panel span and rows per bin: bin b of a span covers its local rows
                                   // [b bin_rows, (b + 1) bin_rows).  Entry e of a probed list:
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
         const int i8_mode = a.info->i8_mode;                 // (read ONCE: in the loop below every use would be a fresh global load)
         const float epsq = a.eps[q];
         const float that1 = select_threshold(unsortable_f32(ans), epsq, i8_mode);
-        const int grows = group_rows_of(i8_mode);            // rows per candidate group (4, or 8 on the int8 scan)
+        const int grows = a.group_rows > 0 ? a.group_rows : group_rows_of(i8_mode);   // rows per candidate group
         if (!(that1 < 0.9e38f)) fb = true;
         int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
         int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
@@ -697,7 +709,7 @@ __global__ __launch_bounds__(128) void ivf_select_kernel(IvfSelectArgs a) {  // 
                     ncq = resc ? 0 : active;
 #pragma unroll
                     for (int i = 0; i < kIvfMaxMinima - 1; ++i) {
-                        crow[i] = row0 + cand_row_offset(__float_as_uint(mv[i]), i8_mode);
+                        crow[i] = row0 + (int)(__float_as_uint(mv[i]) & 0x3Fu) * grows;
                         if (i < ncq && crow[i] + grows > end) resc = true;
                     }
                     if (resc) {

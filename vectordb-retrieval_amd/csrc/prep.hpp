@@ -387,13 +387,33 @@ __device__ __forceinline__ void query_eps_body(int64_t gid, const EpsArgs &a) {
     const double cs = (double)a.info->cs;
     double n2 = 0.0;
     int inexact = 0, notint = 0;
+    auto see = [&](float v) {
+        n2 = fma((double)v, (double)v, n2);
+        const float s = v * bs;
+        inexact |= ((float)(_Float16)s != s);
+        notint |= (v != rintf(v));
+    };
     if (qv) {
-        for (int d = part; d < a.D; d += 16) {
-            const float v = a.Q[(size_t)q * a.D + d];
-            n2 = fma((double)v, (double)v, n2);
-            const float s = v * bs;
-            inexact |= ((float)(_Float16)s != s);
-            notint |= (v != rintf(v));
+        const float *row = a.Q + (size_t)q * a.D;
+        if ((a.D & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Q) & 15) == 0) {
+            // 16 bytes per lane and load, four loads in flight: one value per lane and trip was 24 DEPENDENT round trips per
+            // query at 384 dims -- 20 us of every prep dispatch on a 10 000-query batch
+            const float4 *r4 = reinterpret_cast<const float4 *>(row);
+            const int n4 = a.D >> 2;
+            int i = part;
+            for (; i + 48 < n4; i += 64) {
+                const float4 v0 = r4[i], v1 = r4[i + 16], v2 = r4[i + 32], v3 = r4[i + 48];
+                see(v0.x); see(v0.y); see(v0.z); see(v0.w);
+                see(v1.x); see(v1.y); see(v1.z); see(v1.w);
+                see(v2.x); see(v2.y); see(v2.z); see(v2.w);
+                see(v3.x); see(v3.y); see(v3.z); see(v3.w);
+            }
+            for (; i < n4; i += 16) {
+                const float4 v = r4[i];
+                see(v.x); see(v.y); see(v.z); see(v.w);
+            }
+        } else {
+            for (int d = part; d < a.D; d += 16) see(row[d]);
         }
     }
 #pragma unroll

@@ -177,6 +177,7 @@ struct vdb_index_s {
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
     int ivf_part = 0;                        // option "ivf_part": spans per row part of the IVF list scan (0 auto)
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
+    int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int i8_nt = 0;                           // option "i8_nt": non-temporal staging loads of the serving-shaped int8 scan (0 auto, 1 never, 2 always)
@@ -447,7 +448,11 @@ void build_derived(vdb_index_s *h, hipStream_t st) {
     const int64_t n = h->N;
     // D > 128 (K-loop scan): p16 panels for v_mfma_f32_16x16x32_f16; D <= 128: 32-row tiles (scan_kernel, dense path)
     // (panel_layout 2 = p16 for D <= 128 too, when the corpus is too large for the dense small-corpus kernel)
-    h->tile16 = h->layout_override != 1 && (h->ksteps > kMaxKSteps || (h->layout_override == 2 && n > kDenseMaxRows));
+    // (D > 128 with at most 2048 rows -- an IVF coarse quantizer over embeddings: 32-row tiles, served by the dense path's K-loop
+    //  scores + register select instead of the float64 exhaustive kernel, search_flat.inc)
+    constexpr int64_t kDenseRegRows = 2048;
+    h->tile16 = h->layout_override != 1 && ((h->ksteps > kMaxKSteps && (n > kDenseRegRows || h->layout_override == 2)) ||
+                                            (h->layout_override == 2 && n > kDenseMaxRows));
     const int64_t span_rows = h->tile16 ? kSpanRows16 : kSpanRows;
     h->Npad = (n + span_rows - 1) / span_rows * span_rows;
     h->scan_ok = false;
@@ -954,7 +959,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         s.nlist = h->nlist;
         s.nprobe = h->nprobe;
         s.last_candidates = s.last_rescan_bins = s.last_fallback_queries = 0;
-        s.last_scan_ms = s.last_total_ms = 0.f;
+        s.last_scan_ms = s.last_total_ms = s.last_prep_ms = s.last_tail_ms = 0.f;
         if (h->ws.small.p && (h->last.last_path == VDB_PATH_MFMA_SCAN || (h->last.last_path == VDB_PATH_IVF && h->ivf_last_mfma))) {
             std::vector<unsigned char> buf(kSmallBytes);
             VDB_HIP(hipDeviceSynchronize());
@@ -975,7 +980,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
             s.last_rescan_bins = (int64_t)c[1];
         }
         if (h->ev_used > 0) {  // averages over every search recorded since timing was switched on
-            double scan = 0.0, total = 0.0;
+            double scan = 0.0, total = 0.0, prep = 0.0, tail = 0.0;
             for (size_t i = 0; i < h->ev_used; ++i) {
                 float ms = 0.f;
                 VDB_HIP(hipEventSynchronize(h->ev_total[2 * i + 1]));
@@ -983,9 +988,15 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
                 scan += ms;
                 VDB_HIP(hipEventElapsedTime(&ms, h->ev_total[2 * i], h->ev_total[2 * i + 1]));
                 total += ms;
+                VDB_HIP(hipEventElapsedTime(&ms, h->ev_total[2 * i], h->ev_scan[2 * i]));
+                prep += ms;
+                VDB_HIP(hipEventElapsedTime(&ms, h->ev_scan[2 * i + 1], h->ev_total[2 * i + 1]));
+                tail += ms;
             }
             s.last_scan_ms = (float)(scan / h->ev_used);
             s.last_total_ms = (float)(total / h->ev_used);
+            s.last_prep_ms = (float)(prep / h->ev_used);
+            s.last_tail_ms = (float)(tail / h->ev_used);
         }
         *out = s;
     });
@@ -1055,6 +1066,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_min_batch") {
             if (value < 1 || value > 1e9) throw Error(VDB_ERR_INVALID, "ivf_min_batch must be >= 1");
             h->ivf_min_batch = (int)value;
+        } else if (k == "ivf_group") {
+            if (value != 0 && value != 1 && value != 2 && value != 4) throw Error(VDB_ERR_INVALID, "ivf_group must be 0, 1, 2 or 4");
+            h->ivf_group = (int)value;
         } else if (k == "ivf_nw") {
             if (value != 0 && value != 2 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_nw must be 0, 2, 4 or 8");
             h->ivf_nw = (int)value;
