@@ -231,6 +231,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *     "i8_variant"      0..7: tile / stage / wave shapes of the flat int8 scan (6 / 7: variant 3 with a pacing barrier
  *                       per 1 / 2 tiles)
  *     "i8_group"        8 (default) | 4 rows per select group of the flat int8 scan
+ *     "f16_group"       8 (default) | 4 rows per select group of the fp16 flat scan (D <= 128)
  *     "i8_ring"         0 auto (4) | 2 | 4 | 8 LDS staging stages of the serving-shaped and IVF int8 scans
  *     "i8_nt"           0 (default) / 2: the serving-shaped int8 scan stages its panels with non-temporal loads | 1 off
  *     "ivf_nw"          0 auto | 2 / 4 / 8 waves per IVF work item

@@ -205,8 +205,7 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                     m[0][cb] = fast_min(m[0][cb], v, NEG_INF);
                 };
                 if (GROUP == 4) {
-                    const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
-                                              fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
+                    const float qm = quad_min(acc[t][cb][0], acc[t][cb][1], acc[t][cb][2], acc[t][cb][3], NEG_INF);
                     insert(pack_score(qm, idmask, id));
                 } else if (GROUP == 2) {
                     insert(pack_score(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF), idmask, 2 * id));

@@ -155,6 +155,7 @@ struct RefineListArgs {
     double *pkeys;              // partial mode: [nq][k]
     int64_t *pids;
     int group_shift = -1;       // log2 of the rows per candidate group; -1 = by the scan's arithmetic (quads, octs on the int8 scan)
+    int f16_shift = 2;          // ... of the fp16 scan when group_shift is -1 (3: scan_kernel<.., G8>)
 };
 
 // int8 form of the list refine for one query (wave): W = x8_pitch / 4 dwords per row.  The query's int8 row b = cq - q
@@ -239,7 +240,7 @@ __device__ __forceinline__ void refine_list_body(const RefineListArgs &a, unsign
     nres = nres < a.rescan_cap ? nres : a.rescan_cap;
     const int32_t *cr = a.cand_rows + (size_t)q * a.cand_cap;
     const int mode = a.c.info != nullptr ? a.c.info->i8_mode : 0;
-    const int gshift = a.group_shift >= 0 ? a.group_shift : (mode & 4) ? 3 : 2;   // a candidate = 4 or 8 (or 1 / 2) consecutive rows
+    const int gshift = a.group_shift >= 0 ? a.group_shift : mode ? ((mode & 4) ? 3 : 2) : a.f16_shift;   // a candidate = 4 or 8 (or 1 / 2) consecutive rows
     if (mode != 0 && a.c.X8 != nullptr) {                        // integer batch on a byte-valued corpus: int8 rows
         if (a.c.x8_pitch == 64) refine_list_dot8<KPL, 16>(a, q, ncand, nres, gshift, tk);
         else refine_list_dot8<KPL, 32>(a, q, ncand, nres, gshift, tk);

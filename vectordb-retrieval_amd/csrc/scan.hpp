@@ -63,6 +63,21 @@ __device__ __forceinline__ float fast_min(float a, float b, float neg_inf) {
     return __builtin_amdgcn_fmed3f(a, b, neg_inf);
 }
 
+// Minimum of the four (eight) scores of a quad (oct), straight out of the accumulators, as a LEFT-NESTED fminf chain of odd
+// length: hipcc folds fminf(fminf(x, y), z) into one v_min3_f32 on raw operands, but puts a quieting v_max in front of each
+// operand of a two-operand v_min_f32 (ISA of round 4's first attempt: 2 v_max + v_min + v_min3 per quad -- worse than the three
+// v_med3 it replaced).  The opaque +inf (-neg_inf, a source modifier) pads the chain to an odd count: 2 ops per quad, 4 per oct.
+__device__ __forceinline__ float quad_min(float a, float b, float c, float d, float neg_inf) {
+    return __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fminf(a, b), c), d), -neg_inf);
+}
+__device__ __forceinline__ float oct_min(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
+                                         float neg_inf) {
+    float t = __builtin_fminf(__builtin_fminf(a0, a1), a2);
+    t = __builtin_fminf(__builtin_fminf(t, a3), a4);
+    t = __builtin_fminf(__builtin_fminf(t, a5), a6);
+    return __builtin_fminf(__builtin_fminf(t, a7), -neg_inf);
+}
+
 // ---- phases of one 32-row tile, for one wave (sched_barrier(0) keeps hipcc from blending them) ----------
 // a packed bin minimum names a quad: offset of its first row inside the bin
 // chunk c covers spans [chunk_span0(c), chunk_span0(c+1)): nspans are dealt as evenly as possible so that the
@@ -115,7 +130,11 @@ __device__ __forceinline__ void mfma_phase(const half8 (&fr)[KSTEPS], const half
 // their quad ids, so a bin whose third minimum is above the threshold yields two candidate quads instead of a re-scan
 // of the whole bin: the probed lists of a query are dense in near neighbours and "two close quads in one bin" is
 // common there (0.6-0.9 re-scanned bins per query with the two-minimum guard, a few per hundred with three).
-template <int ABL, bool M3 = false>
+// OCT (flat index, round 4): the group is an OCT -- 8 consecutive rows, two adjacent quads of the lane's 16 -- as on the int8
+// scan: 4 min ops (v_min3 chains on the raw accumulators) + 1 + 2 = 7 VALU ops per 8 scores instead of 5 per 4.  The select is
+// what the D <= 64 scan is bound by (stamps, profiles/r04_stamps_scan_fp16.txt: 441 - 472 cycles of select against 256 of MFMA
+// per tile and wave) and a sixth of the D = 128 scan; the price is twice the rows per candidate in the exact refine.
+template <int ABL, bool M3 = false, bool OCT = false>
 __device__ __forceinline__ void select_phase(const float16v &acc0, const float16v &acc1, float (&m1)[2],
                                              float (&m2)[2], unsigned idmask, float neg_inf, unsigned id0,
                                              float *m3 = nullptr) {
@@ -123,16 +142,30 @@ __device__ __forceinline__ void select_phase(const float16v &acc0, const float16
         asm volatile("" ::"v"(acc0), "v"(acc1));
         return;
     }
+    if (OCT) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float o0 = oct_min(acc0[8 * g], acc0[8 * g + 1], acc0[8 * g + 2], acc0[8 * g + 3], acc0[8 * g + 4],
+                                     acc0[8 * g + 5], acc0[8 * g + 6], acc0[8 * g + 7], neg_inf);
+            const float v0 = pack_score(o0, idmask, (id0 >> 1) + g);
+            m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
+            m1[0] = fast_min(m1[0], v0, neg_inf);
+            const float o1 = oct_min(acc1[8 * g], acc1[8 * g + 1], acc1[8 * g + 2], acc1[8 * g + 3], acc1[8 * g + 4],
+                                     acc1[8 * g + 5], acc1[8 * g + 6], acc1[8 * g + 7], neg_inf);
+            const float v1 = pack_score(o1, idmask, (id0 >> 1) + g);
+            m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
+            m1[1] = fast_min(m1[1], v1, neg_inf);
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < (ABL == 5 ? 2 : 4); ++g) {   // ABL 5: timing-only, half the select work
-        const float q0 = fast_min(fast_min(acc0[4 * g], acc0[4 * g + 1], neg_inf),
-                                  fast_min(acc0[4 * g + 2], acc0[4 * g + 3], neg_inf), neg_inf);
+        const float q0 = quad_min(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3], neg_inf);
         const float v0 = pack_score(q0, idmask, id0 + g);
         if (M3) m3[0] = __builtin_amdgcn_fmed3f(m2[0], m3[0], v0);
         m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], v0);
         m1[0] = fast_min(m1[0], v0, neg_inf);
-        const float q1 = fast_min(fast_min(acc1[4 * g], acc1[4 * g + 1], neg_inf),
-                                  fast_min(acc1[4 * g + 2], acc1[4 * g + 3], neg_inf), neg_inf);
+        const float q1 = quad_min(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3], neg_inf);
         const float v1 = pack_score(q1, idmask, id0 + g);
         if (M3) m3[1] = __builtin_amdgcn_fmed3f(m2[1], m3[1], v1);
         m2[1] = __builtin_amdgcn_fmed3f(m1[1], m2[1], v1);
@@ -164,8 +197,9 @@ __device__ __forceinline__ void read_phase(const half8 *__restrict__ A_tile, con
 // so the per-stage barrier keeps the stagger locked.
 // BT: tiles per level-1 bin per lane half (16 -> 256-row bins for the flat index, 4 -> 64-row bins for IVF,
 // whose per-query row count is small); ITEMS: IVF work-item mode (see ScanArgs).
-template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0, int BT = 16, bool ITEMS = false, int PRIO = 0>
+template <int KSTEPS, int NWAVES, int ST, int WPS, int ABL = 0, int BT = 16, bool ITEMS = false, int PRIO = 0, bool G8 = false>
 __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
+    static_assert(!G8 || (!ITEMS && BT == 16), "octs: flat index, 256-row bins");
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * KSTEPS * 64;           // 16-byte vectors per stage
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
@@ -394,7 +428,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ABL == 4) { asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1)); tb = stamp(); c_mfma += tb - ta; ta = tb; }
                 if (t + 1 < ST) read_phase<KSTEPS>(A + (t + 1) * KSTEPS * 64, B4 + (t + 1) * 8, fr, cin, lane);
-                select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2), m3);
+                select_phase<ABL, ITEMS, G8>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)(((ts0 + t) % BT) << 2), m3);
                 if (ABL == 4) { tb = stamp(); c_sel += tb - ta; ta = tb; }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -423,7 +457,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
                 read_phase<KSTEPS>(A + t * KSTEPS * 64, B4 + t * 8, fr, cin, lane);
                 // retire the previous tile: index tp inside its span (the span before this one when ts0 + t == 0)
                 const int tp = (ts0 + t + TPS - 1) % TPS;
-                select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2), m3);
+                select_phase<ABL, ITEMS, G8>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((tp % BT) << 2), m3);
                 if (t == 0 && st > 0 && (ts0 % BT) == 0)      // (BT % ST == 0: bins only end at stage starts)
                     flush_bin(span0 + (st * ST - 1) / TPS, tp / BT);
                 if (PRIO != 3) __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +471,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
             __syncthreads();
             if (ABL == 4) { tb = stamp(); c_bar += tb - ta; }
         }
-        select_phase<ABL, ITEMS>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2), m3);  // drain the last tile
+        select_phase<ABL, ITEMS, G8>(acc0, acc1, m1, m2, idmask, NEG_INF, (unsigned)((BT - 1) << 2), m3);  // drain the last tile
         flush_bin(span1 - 1, BPS - 1);
     }
     if (ITEMS)       // fill the last vector of this part's run
@@ -641,8 +675,7 @@ __global__ __launch_bounds__(NW * 64, 2) void scan_kloop_kernel(ScanArgs a, Scan
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {       // quad minima, as in select_phase
-                    const float qm = fast_min(fast_min(acc[t][cb][4 * g], acc[t][cb][4 * g + 1], NEG_INF),
-                                              fast_min(acc[t][cb][4 * g + 2], acc[t][cb][4 * g + 3], NEG_INF), NEG_INF);
+                    const float qm = quad_min(acc[t][cb][4 * g], acc[t][cb][4 * g + 1], acc[t][cb][4 * g + 2], acc[t][cb][4 * g + 3], NEG_INF);
                     const float v = pack_score(qm, idmask, id0 + g);
                     m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
                     m1[cb] = fast_min(m1[cb], v, NEG_INF);
@@ -688,6 +721,8 @@ struct SelectArgs {
                                  // superbins -- sb_m1 / sb_m2 alias bin_m1 / bin_m2, sb_span is unused (large k on
                                  // mid-size corpora, where N/256 superbins would be fewer than 4k)
     int cand_cap, rescan_cap;
+    int f16_gmode;               // fp16 scan: 0 = candidate groups are quads, 4 = octs (scan_kernel<.., G8>); the int8 scan says so
+                                 // itself (QueryBatchInfo.i8_mode)
     int32_t *cand_rows;          // [nq][cand_cap]
     int32_t *rescan_rows;        // [nq][rescan_cap]
     int32_t *counts;             // [nq][2]
@@ -752,6 +787,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const float tau = unsortable_f32(ans);
     const int i8_mode = a.info->i8_mode;              // (read ONCE: inside the loops below every use would be a fresh global load)
     const float that = select_threshold(tau, a.eps[q], i8_mode);
+    const int gmode = i8_mode ? i8_mode : a.f16_gmode;     // rows per candidate group: quads, or octs (bit 2)
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
 
     int ncand = 0, nres = 0;  // wave-uniform
@@ -784,7 +820,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                 const unsigned long long smask = __ballot(single), rmask = __ballot(deep);
                 if (single) {
                     const int pos = ncand + __popcll(smask & lt_mask);
-                    if (pos < a.cand_cap) cr[pos] = row0 + cand_row_offset(__float_as_uint(m1), i8_mode);
+                    if (pos < a.cand_cap) cr[pos] = row0 + cand_row_offset(__float_as_uint(m1), gmode);
                 }
                 if (deep) {
                     const int pos = nres + __popcll(rmask & lt_mask);
@@ -803,7 +839,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             if (single) {
                 const int pos = ncand + __popcll(smask & lt_mask);
                 const int hh = s % a.groups;
-                const int row = (sspan * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), i8_mode);
+                const int row = (sspan * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), gmode);
                 if (pos < a.cand_cap) cr[pos] = row;
             }
             ncand += __popcll(smask);
@@ -834,7 +870,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
                     if (cand) {
                         const int pos = ncand + __popcll(cm & lt_mask);
                         if (pos < a.cand_cap)
-                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), i8_mode));
+                            cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), gmode));
                     }
                     if (resc) {
                         const int pos = nres + __popcll(rm & lt_mask);
@@ -904,6 +940,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
     const float tau = unsortable_f32(ans);
     const int i8_mode = a.info->i8_mode;              // (read ONCE, see select_kernel)
     const float that = select_threshold(tau, qvalid ? a.eps[q] : 0.f, i8_mode);
+    const int gmode = i8_mode ? i8_mode : a.f16_gmode;     // rows per candidate group: quads, or octs (bit 2)
     const bool force_fb = a.info->force_fallback || !(that < 0.9e38f) || nsb < a.k;
     __syncthreads();  // counters zeroed
     int *cnt_c = &s_cnt[wave][qi][0], *cnt_r = &s_cnt[wave][qi][1], *cnt_d = &s_cnt[wave][qi][2];
@@ -931,7 +968,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
             if (!(sm2v[e] <= that)) {  // only the superbin minimum matters
                 const int pos = atomicAdd(cnt_c, 1);
                 if (pos < a.cand_cap)
-                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), i8_mode);
+                    cr[pos] = (spanv[e] * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(m1), gmode);
             } else {               // two or more interesting scores: queue the superbin for the cooperative walk below
                 const int pos = atomicAdd(cnt_d, 1);
                 if (pos < kDeepCap) deep[pos] = s;
@@ -970,7 +1007,7 @@ __global__ __launch_bounds__(256, 1) void select_kernel_v2(SelectArgs a) {
                 } else {
                     const int pos = atomicAdd(cnt_c, 1);
                     if (pos < a.cand_cap)
-                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), i8_mode));
+                        cr[pos] = (int)((sp * a.groups + hh) * kBinRows + cand_row_offset(__float_as_uint(bm1), gmode));
                 }
             }
         }

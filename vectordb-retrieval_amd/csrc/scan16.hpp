@@ -133,8 +133,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(ScanArgs a) {
         }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const float qm = fast_min(fast_min(acc[cb][0], acc[cb][1], NEG_INF), fast_min(acc[cb][2], acc[cb][3], NEG_INF),
-                                      NEG_INF);
+            const float qm = quad_min(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3], NEG_INF);
             const float v = pack_score(qm, idmask, id);
             m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
             m1[cb] = fast_min(m1[cb], v, NEG_INF);
@@ -395,8 +394,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kloop_kernel(ScanArgs a, ScanKl
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 if (NARROW && cb >= ncb) continue;       // (its minima stay +inf: nothing reads those columns)
-                const float qm = fast_min(fast_min(acc[t][cb][0], acc[t][cb][1], NEG_INF),
-                                          fast_min(acc[t][cb][2], acc[t][cb][3], NEG_INF), NEG_INF);
+                const float qm = quad_min(acc[t][cb][0], acc[t][cb][1], acc[t][cb][2], acc[t][cb][3], NEG_INF);
                 const float v = pack_score(qm, idmask, id);
                 m2[cb] = __builtin_amdgcn_fmed3f(m1[cb], m2[cb], v);
                 m1[cb] = fast_min(m1[cb], v, NEG_INF);

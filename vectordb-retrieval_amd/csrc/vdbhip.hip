@@ -180,6 +180,7 @@ struct vdb_index_s {
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    int f16_group = 8;                       // ... and of the fp16 flat scan (option "f16_group": 4 or 8)
     int i8_nt = 0;                           // option "i8_nt": non-temporal staging loads of the serving-shaped int8 scan (0 auto, 1 never, 2 always)
     int i8_ring = 0;                         // option "i8_ring": LDS staging stages of the streaming-shaped int8 scans (0 auto, 2, 4, 8)
     // option "graph": a device-resident search that repeats with the same shape and buffers (a serving loop) is captured
@@ -1078,6 +1079,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
+        } else if (k == "f16_group") {         // rows per select group of the fp16 flat scan: 8 (octs, default) or 4 (quads)
+            if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "f16_group must be 4 or 8");
+            h->f16_group = (int)value;
         } else if (k == "i8_nt") {
             if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "i8_nt must be 0, 1 or 2");
             h->i8_nt = (int)value;
