@@ -306,7 +306,12 @@ HOST_IO_NOTE = ("value_host_io = SURVEY 8(d): wall clock of <plugin>.batch_searc
 
 def pipeline_of(st, nq, build_s, corpus_bytes):
     res = float(st["bytes_resident"])
+    ws = float(st.get("bytes_workspace", 0))
     return {"path": st["last_path_name"], "candidates_per_query": round(st["last_candidates"] / nq, 2),
+            "hbm_index_mb": round((res - ws) / 2 ** 20, 1), "hbm_workspace_mb": round(ws / 2 ** 20, 1),
+            "hbm_index_over_corpus": round((res - ws) / max(corpus_bytes, 1), 3),
+            "layout": {0: "float32 rows + fp16 scan copy", 1: "float32 rows + fp16 and int8 scan copies",
+                       2: "int8 rows + int8 scan copy only (option int8_only)"}.get(int(st.get("has_i8_copy", 0)), "?"),
             "rescan_bins": int(st["last_rescan_bins"]), "fallback_queries": int(st["last_fallback_queries"]),
             "corpus_fp16_exact": int(st["corpus_fp16_exact"]), "build_s": round(build_s, 3),
             "hbm_resident_mb": round(res / 2 ** 20, 1), "corpus_mb": round(corpus_bytes / 2 ** 20, 1),
@@ -319,7 +324,7 @@ def scan_dtype_name(st) -> str:
 
 
 def flat_leg(vdbhip, torch, name, dev, local_rank, stream, steps, warmup, cpu_budget_s=6.0, host_io=True,
-             data=None, keep_index=False, all_cpu_legs=False):
+             data=None, keep_index=False, all_cpu_legs=False, engine_options=None):
     """One brute-force workload through the plugin: build, host-I/O timing, device-resident timed loop with the scan's
     HIP-event roofline, recall against a CPU leg on a bounded query sample."""
     n, d = WORKLOADS[name][:2]
@@ -327,10 +332,11 @@ def flat_leg(vdbhip, torch, name, dev, local_rank, stream, steps, warmup, cpu_bu
     n, d = X.shape
     nq = Q.shape[0]
     t0 = time.perf_counter()
-    algo = vdbhip.get_algorithm_instance("HipExactSearch", d, name="bench", metric=metric, device=local_rank)
+    extra = {"engine_options": dict(engine_options)} if engine_options else {}
+    algo = vdbhip.get_algorithm_instance("HipExactSearch", d, name="bench", metric=metric, device=local_rank, **extra)
     algo.build_index(X)
     build_s = time.perf_counter() - t0
-    leg = {}
+    leg = {"engine_options": dict(engine_options)} if engine_options else {}
     if host_io:
         leg.update(host_io_timing(algo, Q, k))
     index = algo.index
@@ -789,6 +795,14 @@ def single_gpu_line(args, workload, vdbhip, torch, dev, local_rank, stream, cpu_
     also = {}
     also["serving"] = {"sift1m": serving_leg(vdbhip, torch, dev, local_rank, stream, index, q_t, k, n, d, "sift1m")}
     index.close()
+    # the same corpus and queries on an int8-only index (engine option `int8_only`: the reference holds ONE copy of the corpus,
+    # exact_search.py:34-39): footprint and rate, ids against the headline's
+    lean, lkept = flat_leg(vdbhip, torch, workload, dev, local_rank, stream, args.steps, args.warmup, cpu_budget_s=0.0,
+                           data=(X, Q, k, metric), keep_index=True, engine_options={"int8_only": 1})
+    lean["ids_equal_default_index"] = bool(np.array_equal(lkept[7], ids))
+    lkept[1].close()
+    del lkept
+    also["sift1m_int8_only"] = lean
     del X, Q, kept, algo
     also["gaussian1m"] = flat_leg(vdbhip, torch, "gaussian1m", dev, local_rank, stream, args.steps, args.warmup,
                                   cpu_budget_s=cpu_budget * 0.7)

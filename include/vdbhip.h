@@ -74,12 +74,14 @@ typedef struct vdb_stats_s {
     int32_t nlist;             /* IVF: number of inverted lists (0 = flat index) */
     int32_t nprobe;
     int32_t scan_dtype;        /* arithmetic of the last MFMA scan: 0 = fp16 (f32 accumulate), 1 = int8 (i32 accumulate) */
-    int32_t has_i8_copy;       /* 1 if the index holds the int8 scan copy (byte-valued integer corpus, D <= 128) */
+    int32_t has_i8_copy;       /* 1 if the index holds the int8 scan copy (byte-valued integer corpus, D <= 128) next to the float32
+                                  rows and the fp16 copy; 2 if it holds ONLY the int8 copies (option "int8_only") */
     int64_t last_rows_scanned; /* IVF: (query, row) pairs scanned by the last search (rows of the probed lists) */
     int64_t upload_blocks;     /* row blocks the last vdb_add / vdb_ivf_add streamed through the pinned staging buffers */
     int64_t graph_replays;     /* searches served by launching the captured hipGraph (option "graph") since the handle was made */
     int32_t ndevices;          /* shards of the handle: 1, or the ndev of vdb_create_multi (sums / maxima over the shards above) */
     int32_t reserved0;
+    int64_t bytes_workspace;   /* the part of bytes_resident that is per-search workspace (bin arrays, work lists, staging) */
     float last_prep_ms;        /* timing on: mean time from the start of the device pipeline to the start of the dominant kernel
                                   (query statistics / operands; IVF: + coarse search, plan) ... */
     float last_tail_ms;        /* ... and from its end to the end of the pipeline (bin select + exact refine): with last_scan_ms
@@ -204,6 +206,16 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       takes effect at the next vdb_add
  *     "panel_dtype"     0 auto: byte-valued integer corpora are ALSO kept as an int8 scan copy, and integer query batches
  *                       in the byte window are scanned with int8 MFMA | 1 fp16 scan only
+ *     "int8_only"       flat index, D <= 128, more than 32 768 rows, takes effect at the next vdb_add: 0 (default) | 1: a byte-valued
+ *                       corpus (every value an integer in 0..255 or in -128..127) keeps ONLY its int8 copies -- row-major int8 rows
+ *                       + int8 MFMA panels + their accumulator inits, 0.55x the float32 bytes instead of 3x (the reference holds
+ *                       one copy of the corpus, exact_search.py:34-39).  Same results: integer query batches take the int8 scan
+ *                       and the integer refine as always; a batch with a non-integer value is scanned in fp16 over slabs converted
+ *                       from the int8 panels per search (option "int8_slab_chunks", default 8 scan chunks = 16 MiB of scratch at
+ *                       D = 128) and refined in float64 from x = byte + cx.  The rows stream through in blocks at build time (a
+ *                       100M x 128 shard never exists in float32 inside the library).  Built by ONE add: appending is
+ *                       VDB_ERR_UNSUPPORTED; a corpus that is not byte-valued silently gets the default layout
+ *                       (vdb_stats.has_i8_copy tells: 2 = int8 only)
  *     "stream_panels"   D > 128, takes effect at the next vdb_add: 0 (default) the fp16 scan copy stays resident next to the
  *                       float32 rows | 1 it is NOT kept: every search converts the float32 rows slab by slab into one
  *                       scratch slab and scans that (same results; 1.8x -> ~1.15x the corpus bytes resident for a corpus that

@@ -66,6 +66,43 @@ __device__ __forceinline__ uint64_t exact_key(const float *__restrict__ x, const
     }
 }
 
+// The same key from the int8 row copy of a byte-valued corpus (int8-only indexes keep no float32 rows): x = byte + cx exactly,
+// then the identical float64 chain -- bit-identical keys.  x8 has room for D4 bytes (padding bytes hold -cx, i.e. x = 0).
+template <int U = 16>
+__device__ __forceinline__ uint64_t exact_key_i8(const signed char *__restrict__ x8, int cx, const float *__restrict__ q,
+                                                 int D4, int metric) {
+    const int *xw = reinterpret_cast<const int *>(x8);
+    const float4 *qv = reinterpret_cast<const float4 *>(q);
+    double acc = 0.0;
+#pragma unroll U
+    for (int i = 0; i < D4 / 4; ++i) {
+        const int w = xw[i];
+        const float4 b = qv[i];
+        const double x0 = (double)((int)(signed char)(w & 0xff) + cx), x1 = (double)((int)(signed char)((w >> 8) & 0xff) + cx);
+        const double x2 = (double)((int)(signed char)((w >> 16) & 0xff) + cx), x3 = (double)((w >> 24) + cx);
+        if (metric == 0) {
+            double t;
+            t = x0 - (double)b.x; acc = fma(t, t, acc);
+            t = x1 - (double)b.y; acc = fma(t, t, acc);
+            t = x2 - (double)b.z; acc = fma(t, t, acc);
+            t = x3 - (double)b.w; acc = fma(t, t, acc);
+        } else {
+            acc = fma((double)b.x, x0, acc);
+            acc = fma((double)b.y, x1, acc);
+            acc = fma((double)b.z, x2, acc);
+            acc = fma((double)b.w, x3, acc);
+        }
+    }
+    return sortable_u64(metric == 0 ? acc : -acc);
+}
+
+// key of corpus row `row`: from the float32 rows, or (c.X == nullptr: int8-only index) from the int8 row copy
+template <int U = 16>
+__device__ __forceinline__ uint64_t row_key(const RefineCommon &c, int64_t row, const float *__restrict__ q) {
+    if (c.X) return exact_key<U>(c.X + (size_t)row * c.D4, q, c.D4, c.metric);
+    return exact_key_i8<U>(c.X8 + (size_t)row * c.x8_pitch, c.cx, q, c.D4, c.metric);
+}
+
 // QB keys of ONE row against QB queries: the row is fetched once; every query keeps its own sequential chain, so each
 // key is bit-identical to exact_key().
 template <int QB>
@@ -108,7 +145,7 @@ __device__ __forceinline__ void scan_rows(WaveTopK<KPL> &tk, const RefineCommon 
         const int64_t row = base + lane;
         const bool valid = row < row1;
         uint64_t key = ~0ull;
-        if (valid) key = exact_key<U>(c.X + (size_t)row * c.D4, qptr, c.D4, c.metric);
+        if (valid) key = row_key<U>(c, row, qptr);
         tk.offer(key, c.idmap ? (valid ? c.idmap[row] : -1) : c.id_base + row, valid);
     }
 }
@@ -251,7 +288,7 @@ __device__ __forceinline__ void refine_list_body(const RefineListArgs &a, unsign
             int64_t row = valid ? (int64_t)cr[i >> gshift] + (i & ((1 << gshift) - 1)) : 0;
             valid = valid && row < a.c.N;
             uint64_t key = ~0ull;
-            if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+            if (valid) key = row_key(a.c, row, qptr);
             tk.offer(key, a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row, valid);
         }
         const int32_t *rr = a.rescan_rows + (size_t)q * a.rescan_cap * 2;
@@ -374,7 +411,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
         const int64_t row = id - a.c.id_base;
         valid = valid && id >= 0 && row >= 0 && row < a.c.N;
         uint64_t key = ~0ull;
-        if (valid) key = exact_key(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric);
+        if (valid) key = row_key(a.c, row, qptr);
         tk.offer(key, id, valid);
     }
     const size_t o = (size_t)q * a.c.k;
@@ -455,7 +492,15 @@ __global__ __launch_bounds__(256) void refine_full_blocked_kernel(RefineFullArgs
             uint64_t key[QB];
 #pragma unroll
             for (int j = 0; j < QB; ++j) key[j] = ~0ull;
-            if (valid) exact_keys<QB>(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric, key);
+            if (valid) {
+                if (a.c.X) {
+                    exact_keys<QB>(a.c.X + (size_t)row * a.c.D4, qptr, a.c.D4, a.c.metric, key);
+                } else {            // int8-only index: the int8 row, once per query (same chains, same keys)
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+                        key[j] = exact_key_i8<4>(a.c.X8 + (size_t)row * a.c.x8_pitch, a.c.cx, qptr[j], a.c.D4, a.c.metric);
+                }
+            }
             const int64_t id = a.c.idmap ? (valid ? a.c.idmap[row] : -1) : a.c.id_base + row;
 #pragma unroll
             for (int j = 0; j < QB; ++j) tk[j].offer(key[j], id, valid);

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_kernel(ScanArgs a) {
         const int ci = j / a.nqtiles, qt = j - ci * a.nqtiles;
         chunk = x + 8 * ci;
         if (chunk >= a.nchunks) return;
+        chunk += a.chunk0;                                  // (a slab launch of an int8-only index: chunks [chunk0, chunk0 + nchunks))
         q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;       // first query of this wave
         span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
         span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);

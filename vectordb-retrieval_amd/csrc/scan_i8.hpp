@@ -21,15 +21,19 @@ typedef int int16v __attribute__((ext_vector_type(16)));
 // ---- build: int8 panels in A-fragment order --------------------------------------------------------------------------
 // panels8[tile][ks][lane][16 x int8]: lane l holds MFMA row (l & 31) -- same row mapping as the fp16 panels -- dims
 // 32*ks + 16*(l >> 5) .. +15, value x - cx (0 beyond D or N).  One thread per (tile, ks, lane).
+// (tile0: tiles [tile0, tile0 + ntiles) are written, to panels[tile0 ...) -- the whole corpus (0), or one row block of an
+//  int8-only build, where X is the block's base minus the rows in front of it: only rows of the block are touched)
 __global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
                                                               int ks32, int64_t ntiles, int cx,
-                                                              int4v *__restrict__ panels) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                              int4v *__restrict__ panels, int64_t tile0 = 0) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
     const int ks = (int)(tk % ks32);
-    const int64_t tile = tk / ks32;
+    int64_t tile = tk / ks32;
     if (tile >= ntiles) return;
+    tile += tile0;
+    gid += tile0 * ks32 * 64;
     const int rho = lane & 31, kh = lane >> 5;
     const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
     const int64_t span = tile / kTilesPerSpan;
@@ -55,11 +59,12 @@ __global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__res
 // accumulator init per row, for both query windows: bias8[w][row], w = 0 (cq = 127), 1 (cq = -1)
 //   L2: floor((||x||^2 - 2 cq sum(x)) / 2) + kI8Offset     IP: -cq sum(x) + kI8Offset     padding rows: kI8PadBias
 // (also rowstat[row] = {sum x^2, sum x} for the int8 list refine, refine.hpp)
+// (row0 / row1: rows [row0, row1) only -- one row block of an int8-only build; default: all Npad rows)
 __global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restrict__ X, int64_t N, int64_t Npad, int D,
                                                             int D4, int metric, int32_t *__restrict__ bias8,
-                                                            int *__restrict__ rowstat) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= Npad) return;
+                                                            int *__restrict__ rowstat, int64_t row0 = 0, int64_t row1 = -1) {
+    const int64_t row = row0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (row1 < 0 ? Npad : row1)) return;
     if (row >= N) {
         bias8[row] = kI8PadBias;
         bias8[Npad + row] = kI8PadBias;
@@ -134,6 +139,52 @@ __global__ __launch_bounds__(256) void build_rows_i8_kernel(const float *__restr
         word |= ((unsigned)v & 0xffu) << (8 * b);
     }
     reinterpret_cast<unsigned *>(rows)[gid] = word;
+}
+
+// ---- int8-only indexes (option "int8_only"): the fp16 scan copy of a slab of tiles, converted from the int8 panels per search ---
+// fp16 piece (tile, 16-dim k-step ks, lane = (row rho, k half kh)) = dims [16 ks + 8 kh, +8) of MFMA row rho = 8 consecutive bytes
+// of the int8 piece (tile, ks / 2, lane' = rho + 32 * ((ks & 1) * 16 + 8 kh >= 16)) -- values byte + cx, exact in fp16.  Rows past N and
+// dims past D hold A = 0 in the int8 panels (x = cx there), so those positions must come out as 0: `N`, `D` are re-checked here.
+// Returns at once when the batch is served by the int8 scan (the usual case: the slab is the price of deciding on the device).
+__global__ __launch_bounds__(256) void convert_slab_from_i8_kernel(const int4v *__restrict__ panels8, int ks32, int ksteps, int cx,
+                                                                   int64_t tile0, int64_t ntiles, int64_t N, int D,
+                                                                   const QueryBatchInfo *__restrict__ info,
+                                                                   half8 *__restrict__ out) {
+    if (info->i8_mode) return;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t tk = gid >> 6;
+    const int ks = (int)(tk % ksteps);
+    const int64_t tl = tk / ksteps;
+    if (tl >= ntiles) return;
+    const int64_t tile = tile0 + tl;
+    const int rho = lane & 31, kh = lane >> 5;
+    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+    const int64_t span = tile / kTilesPerSpan;
+    const int t = (int)(tile - span * kTilesPerSpan);
+    const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+    const int o = (ks & 1) * 16 + kh * 8;                       // dim offset inside the 32-dim int8 k-step
+    const int4v src = panels8[((size_t)tile * ks32 + (ks >> 1)) * 64 + rho + 32 * (o >> 4)];
+    const int w0 = src[(o & 15) >> 2], w1 = src[((o & 15) >> 2) + 1];
+    const int d0 = ks * 16 + kh * 8;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b = (j < 4 ? (w0 >> (8 * j)) : (w1 >> (8 * (j - 4)))) & 0xff;
+        const int x = (int)(signed char)b + cx;
+        v[j] = (_Float16)((row < N && d0 + j < D) ? (float)x : 0.f);
+    }
+    out[gid] = v;
+}
+
+// queries for vdb_reserve on an int8-only index: corpus rows as float32 (x = byte + cx)
+__global__ __launch_bounds__(256) void rows_i8_to_float_kernel(const signed char *__restrict__ rows8, int pitch, int cx, int64_t n,
+                                                               int D, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int64_t row = i / D;
+    const int d = (int)(i - row * D);
+    out[i] = (float)((int)rows8[(size_t)row * pitch + d] + cx);
 }
 
 // ---- the scan ------------------------------------------------------------------------------------------------------

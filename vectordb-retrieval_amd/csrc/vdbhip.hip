@@ -181,6 +181,14 @@ struct vdb_index_s {
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int f16_group = 8;                       // ... and of the fp16 flat scan (option "f16_group": 4 or 8)
+    // option "int8_only" (takes effect at the next add; flat index, D <= 128, > 32768 rows, byte-valued corpus): only the int8
+    // copies are kept -- rows8 + panels8 + their biases, 0.55x the float32 corpus instead of 3x.  Integer query batches run as on
+    // the default index; a batch with a non-integer value is scanned in fp16 over slabs converted from the int8 panels per search;
+    // the exact kernels read x = byte + cx from the int8 rows (same float64 chains, same keys).  One add builds it (no append).
+    int int8_only_opt = 0;
+    bool int8_only = false;
+    int64_t int8_slab_chunks = 0;            // option "int8_slab_chunks": scan chunks per converted fp16 slab (0 = default 8)
+    int64_t int8_block_rows = 0;             // option "int8_block_rows": rows per ingestion block of the int8-only build (0 = 4M; tests)
     int i8_nt = 0;                           // option "i8_nt": non-temporal staging loads of the serving-shaped int8 scan (0 auto, 1 never, 2 always)
     int i8_ring = 0;                         // option "i8_ring": LDS staging stages of the streaming-shaped int8 scans (0 auto, 2, 4, 8)
     // option "graph": a device-resident search that repeats with the same shape and buffers (a serving loop) is captured
@@ -516,6 +524,104 @@ void ingest_rows(vdb_index_s *h, int64_t row0, const float *x_dev_or_host, bool 
         upload_rows(h, dst, D4, x_dev_or_host, n, D, st);
 }
 
+// ---- int8-only build (option "int8_only") ----------------------------------------------------------------------------------
+// The float32 rows are never resident as a whole: they pass through in blocks (a window of the caller's device array when its
+// rows are 16-byte multiples, else a padded / uploaded temporary of <= 4M rows), and every block leaves only its int8 rows, row
+// statistics, int8 panels and accumulator inits behind.  The byte window (u8: x - 128, s8: x) is taken from the first block
+// and checked on the flags of all of them; if the other window fits the whole corpus the build runs once more with it.
+// Returns false when the corpus is not byte-valued (the caller then builds the default index).
+constexpr int64_t kInt8OnlyMinRows = 32768;
+bool build_int8_only(vdb_index_s *h, const float *x, bool on_device, int64_t n, hipStream_t st) {
+    const int D = h->dim, D4 = h->D4;
+    DevBuf *gone[] = {&h->x32, &h->panels, &h->slab};
+    for (auto b : gone) b->release();
+    h->Npad = (n + kSpanRows - 1) / kSpanRows * kSpanRows;
+    h->i8_ks = D <= 64 ? 2 : 4;
+    h->rows8_pitch = h->i8_ks * 32;
+    const int64_t ntiles = h->Npad / kTileRows;
+    h->rows8.reserve((size_t)n * h->rows8_pitch);
+    h->rowstat8.reserve((size_t)n * 2 * sizeof(int));
+    h->xnorm2.reserve((size_t)n * sizeof(float));
+    h->stats.reserve(sizeof(IndexStats));
+    h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
+    h->panels8.reserve((size_t)ntiles * h->i8_ks * 64 * sizeof(int4v));
+    h->bias.reserve((size_t)h->Npad * sizeof(float));
+    const bool direct = on_device && D4 == D && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int64_t block_want = h->int8_block_rows > 0 ? (h->int8_block_rows + kSpanRows - 1) / kSpanRows * kSpanRows : (int64_t)4 << 20;
+    const int64_t block_rows = std::min<int64_t>((n + kSpanRows - 1) / kSpanRows * kSpanRows, block_want);
+    ScopedDevBuf tmp;
+    if (!direct) tmp.reserve((size_t)std::min<int64_t>(block_rows, n) * D4 * sizeof(float));
+    IndexStats hs{};
+    int cx = -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        VDB_HIP(hipMemsetAsync(h->stats.p, 0, sizeof(IndexStats), st));
+        for (int64_t r0 = 0; r0 < n; r0 += block_rows) {
+            const int64_t r1 = std::min<int64_t>(n, r0 + block_rows), nb = r1 - r0;
+            const bool last = r1 == n;
+            const float *blk;
+            if (direct) {
+                blk = x + (size_t)r0 * D;
+            } else {
+                float *dst = tmp.as<float>();
+                if (D4 != D) VDB_HIP(hipMemsetAsync(dst, 0, (size_t)nb * D4 * sizeof(float), st));
+                if (on_device)
+                    VDB_HIP(hipMemcpy2DAsync(dst, (size_t)D4 * 4, x + (size_t)r0 * D, (size_t)D * 4, (size_t)D * 4, (size_t)nb,
+                                             hipMemcpyDeviceToDevice, st));
+                else
+                    upload_rows(h, dst, D4, x + (size_t)r0 * D, nb, D, st);
+                blk = dst;
+            }
+            corpus_stats_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st>>>(blk, nb, D4, h->xnorm2.as<float>() + r0,
+                                                                                        h->stats.as<IndexStats>());
+            if (cx < 0) {           // the window: from the first block's flags
+                VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+                VDB_HIP(hipStreamSynchronize(st));
+                if (hs.nonfinite || (hs.not_u8 && hs.not_s8)) return false;
+                cx = !hs.not_u8 ? 128 : 0;
+            }
+            const int64_t words = nb * (h->rows8_pitch / 4);
+            build_rows_i8_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(
+                blk, nb, D, D4, h->rows8_pitch, cx, h->rows8.as<signed char>() + (size_t)r0 * h->rows8_pitch);
+            // (panels and accumulator inits index rows globally: base pointer moved back by the rows in front of the block)
+            const float *fake = blk - (size_t)r0 * D4;
+            const int64_t row_end = last ? h->Npad : r1;
+            const int64_t t0 = r0 / kTileRows, nt = (row_end - r0) / kTileRows;
+            build_panels_i8_kernel<<<dim3((unsigned)((nt * h->i8_ks * 64 + 255) / 256)), dim3(256), 0, st>>>(
+                fake, r1, D, D4, h->i8_ks, nt, cx, h->panels8.as<int4v>(), t0);
+            build_bias_i8_kernel<<<dim3((unsigned)((row_end - r0 + 255) / 256)), dim3(256), 0, st>>>(
+                fake, r1, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>(), h->rowstat8.as<int>(), r0, row_end);
+            VDB_HIP(hipGetLastError());
+            if (!direct) VDB_HIP(hipStreamSynchronize(st));     // (the temporary is refilled by the next block)
+        }
+        VDB_HIP(hipMemcpyAsync(&hs, h->stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        if (hs.nonfinite) return false;
+        const bool fits = cx == 128 ? !hs.not_u8 : !hs.not_s8;
+        if (fits) break;
+        const bool other = cx == 128 ? !hs.not_s8 : !hs.not_u8;
+        if (!other || attempt == 1) return false;
+        cx = cx == 128 ? 0 : 128;       // a later block left the first block's window but the whole corpus fits the other one
+    }
+    memcpy(&h->absmax, &hs.absmax_bits, 4);
+    memcpy(&h->maxnorm2, &hs.maxnorm2_bits, 4);
+    h->nonfinite = false;
+    h->corpus_int_unscaled = true;      // integers 0..255 / -128..127: stored unscaled, exact in fp16
+    h->corpus_fp16_exact = true;
+    h->sx = 1.f;
+    h->i8_cx = cx;
+    h->i8_ok = true;
+    h->tile16 = false;
+    h->panels_streamed = false;
+    build_bias_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(h->xnorm2.as<float>(), n, h->Npad, h->metric,
+                                                                                    h->bias.as<float>());
+    VDB_HIP(hipGetLastError());
+    VDB_HIP(hipStreamSynchronize(st));
+    h->int8_only = true;
+    h->scan_ok = true;
+    h->built = true;
+    return true;
+}
+
 // the index holds exactly these n rows afterwards (whatever it held before)
 void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int64_t n, int64_t id_base,
                  hipStream_t st) {
@@ -527,6 +633,23 @@ void build_index(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     h->ivf_list_of_row.clear();
     h->N = n;
     h->id_base = id_base;
+    h->int8_only = false;
+    if (h->int8_only_opt && h->dim <= 128 && n > kInt8OnlyMinRows && !h->coarse) {
+        bool ok = false;
+        try {
+            ok = build_int8_only(h, x_dev_or_host, on_device, n, st);
+        } catch (...) {
+            h->N = 0;
+            h->built = false;
+            h->scan_ok = false;
+            h->int8_only = false;
+            throw;
+        }
+        if (ok) return;
+        h->int8_only = false;          // not byte-valued: the default layout (vdb_stats: has_i8_copy says which one it is)
+        DevBuf *i8[] = {&h->rows8, &h->rowstat8, &h->bias8, &h->panels8};
+        for (auto b : i8) b->release();
+    }
     try {
         if (n > 0) {
             h->x32.reserve((size_t)n * h->D4 * sizeof(float));
@@ -557,6 +680,9 @@ void append_rows(vdb_index_s *h, const float *x_dev_or_host, bool on_device, int
     if (n < 0) throw Error(VDB_ERR_INVALID, "negative row count");
     require_same_id_base(h, id_base);
     if (n == 0) return;
+    if (h->int8_only)
+        throw Error(VDB_ERR_UNSUPPORTED, "an int8_only index keeps no float32 rows to re-derive its scan copies from: it is built by "
+                                         "ONE add (vdb_reset, then add everything)");
     if (h->N + n > 2147483647ll - 1024) throw Error(VDB_ERR_UNSUPPORTED, "more than 2^31 rows per shard");
     graph_reset(h);
     VDB_HIP(hipDeviceSynchronize());                        // (searches of the rows about to move may still run)
@@ -725,6 +851,7 @@ int vdb_reset(vdb_handle hh) {
         h->built = false;
         h->scan_ok = false;
         h->ivf_built = false;
+        h->int8_only = false;
         h->ivf_list_of_row.clear();
         h->ivf_offsets_host.clear();
         // faiss.Index.reset frees its storage: so do we (rows, scan copies, CSR arrays; the workspace and an IVF index's
@@ -861,7 +988,12 @@ void rerank_device_impl(vdb_index_s *h, const float *dq, int64_t nq, const int64
         qpad = h->ws.qpad.as<float>();
     }
     RerankArgs a{};
-    a.c = RefineCommon{h->x32.as<float>(), qpad, h->N, h->id_base, h->D4, h->metric, k, nullptr};
+    a.c = RefineCommon{h->int8_only ? nullptr : h->x32.as<float>(), qpad, h->N, h->id_base, h->D4, h->metric, k, nullptr};
+    if (h->int8_only) {
+        a.c.X8 = h->rows8.as<signed char>();
+        a.c.x8_pitch = h->rows8_pitch;
+        a.c.cx = h->i8_cx;
+    }
     a.nq = nq;
     a.cand = cand;
     a.ncand = ncand;
@@ -939,7 +1071,8 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
                                               h->coarse->bias.cap + h->coarse->ws.bytes() -
                                               (h->coarse->ws.small.borrowed ? h->coarse->ws.small.cap : 0));
         }
-        s.has_i8_copy = h->i8_ok ? 1 : 0;
+        s.has_i8_copy = h->int8_only ? 2 : (h->i8_ok ? 1 : 0);
+        s.bytes_workspace = (int64_t)h->ws.bytes();
         s.upload_blocks = h->last_upload_blocks;
         s.graph_replays = h->graph_replays;
         s.last_rows_scanned = 0;
@@ -1079,6 +1212,15 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
+        } else if (k == "int8_only") {
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "int8_only must be 0 or 1");
+            h->int8_only_opt = (int)value;
+        } else if (k == "int8_block_rows") {
+            if (value < 0 || value > 2147483647.0) throw Error(VDB_ERR_INVALID, "int8_block_rows out of range");
+            h->int8_block_rows = (int64_t)value;
+        } else if (k == "int8_slab_chunks") {
+            if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "int8_slab_chunks out of range");
+            h->int8_slab_chunks = (int64_t)value;
         } else if (k == "f16_group") {         // rows per select group of the fp16 flat scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "f16_group must be 4 or 8");
             h->f16_group = (int)value;
