@@ -79,6 +79,17 @@ struct DevBuf {
         cap = want;
         alloc_note("A", p, cap);
     }
+    // exactly `bytes` (no growth slack): buffers of an index that is built once and never grows (int8-only build)
+    void reserve_exact(size_t bytes) {
+        if (bytes == cap && p) return;
+        if (borrowed) throw Error(VDB_ERR_INVALID, "internal: a borrowed device buffer cannot grow");
+        release();
+        g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { p = nullptr; throw Error(VDB_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+        cap = bytes ? bytes : 16;
+        alloc_note("A", p, cap);
+    }
     // reserve that keeps the first `keep` bytes (append): old and new allocation coexist for the copy
     void grow(size_t bytes, size_t keep) {
         if (bytes <= cap) return;
@@ -177,6 +188,7 @@ struct vdb_index_s {
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
     int ivf_part = 0;                        // option "ivf_part": spans per row part of the IVF list scan (0 auto)
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
+    int ivf_i8_group = 4;                    // option "ivf_i8_group": rows per candidate group of the int8 list scan (4 | 8)
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
@@ -539,13 +551,13 @@ bool build_int8_only(vdb_index_s *h, const float *x, bool on_device, int64_t n, 
     h->i8_ks = D <= 64 ? 2 : 4;
     h->rows8_pitch = h->i8_ks * 32;
     const int64_t ntiles = h->Npad / kTileRows;
-    h->rows8.reserve((size_t)n * h->rows8_pitch);
-    h->rowstat8.reserve((size_t)n * 2 * sizeof(int));
+    h->rows8.reserve_exact((size_t)n * h->rows8_pitch);
+    h->rowstat8.reserve_exact((size_t)n * 2 * sizeof(int));
     h->xnorm2.reserve((size_t)n * sizeof(float));
     h->stats.reserve(sizeof(IndexStats));
-    h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
-    h->panels8.reserve((size_t)ntiles * h->i8_ks * 64 * sizeof(int4v));
-    h->bias.reserve((size_t)h->Npad * sizeof(float));
+    h->bias8.reserve_exact((size_t)2 * h->Npad * sizeof(int32_t));
+    h->panels8.reserve_exact((size_t)ntiles * h->i8_ks * 64 * sizeof(int4v));
+    h->bias.reserve_exact((size_t)h->Npad * sizeof(float));
     const bool direct = on_device && D4 == D && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const int64_t block_want = h->int8_block_rows > 0 ? (h->int8_block_rows + kSpanRows - 1) / kSpanRows * kSpanRows : (int64_t)4 << 20;
     const int64_t block_rows = std::min<int64_t>((n + kSpanRows - 1) / kSpanRows * kSpanRows, block_want);
@@ -616,6 +628,7 @@ bool build_int8_only(vdb_index_s *h, const float *x, bool on_device, int64_t n, 
                                                                                     h->bias.as<float>());
     VDB_HIP(hipGetLastError());
     VDB_HIP(hipStreamSynchronize(st));
+    h->xnorm2.release();                // (the float norms only fed `bias`)
     h->int8_only = true;
     h->scan_ok = true;
     h->built = true;
@@ -1200,6 +1213,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_min_batch") {
             if (value < 1 || value > 1e9) throw Error(VDB_ERR_INVALID, "ivf_min_batch must be >= 1");
             h->ivf_min_batch = (int)value;
+        } else if (k == "ivf_i8_group") {
+            if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_i8_group must be 4 or 8");
+            h->ivf_i8_group = (int)value;
         } else if (k == "ivf_group") {
             if (value != 0 && value != 1 && value != 2 && value != 4) throw Error(VDB_ERR_INVALID, "ivf_group must be 0, 1, 2 or 4");
             h->ivf_group = (int)value;
