@@ -12,7 +12,11 @@ WANT = {  # pass group -> (json key, substrings the kernel name must contain)
     "ivf8": ("ivf1024_nprobe8", ("scan_i8_kernel", "true")),
     "ivf128": ("ivf1024_nprobe128", ("scan_i8_kernel", "true")),
     "msmarco": ("msmarco_ivf_nprobe32", ("ivf_kloop_scan_kernel",)),
+    "ivf32": ("ivf1024_nprobe32", ("scan_i8_kernel", "true")),
+    "gaussian": ("gaussian1m", ("scan_kernel<8",)),
+    "glove": ("glove1.2m", ("scan_kernel<4",)),
 }
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r03"
 CORR = ("gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced streams (global_load / LDS-DMA alike) -> doubled; "
         "WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)")
 vals = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
@@ -39,7 +43,7 @@ for group, (key, must) in WANT.items():
     table[key] = {"kernel": kernel.replace("void vdb::", "").replace("(vdb::ScanI8Args)", "").replace(" ", ""),
                   "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
                   "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "launches_averaged": launches, "correction": CORR,
-                  "source": f"profiles/r03_pmc_summary.txt (scripts/final_profiles_r03.sh, separate --pmc passes '{group}_fetch' / '{group}_write')",
+                  "source": f"profiles/{TAG}_pmc_summary.txt (scripts/final_profiles_{TAG}.sh, separate --pmc passes '{group}_fetch' / '{group}_write')",
                   **keep}
     print(key, table[key]["hbm_bytes_per_launch"])
 json.dump(table, open(out, "w"), indent=1)

@@ -69,12 +69,27 @@ def test_random_shapes_and_distributions_bit_exact(oracle, target, i, n, d, nq, 
         X[n // 2] = X[n // 3]
         X[n // 5] = 0.0
         Q[0] = X[n // 7]
-    idx = vdbhip.FlatIndex(d, metric, 0)
+    # round 4: every third case runs on another form of the engine (same results whatever the form): several shards in one
+    # handle (vdb_create_multi), an int8-only index (byte-valued corpora of > 32 768 rows take it, the rest fall back to the
+    # default layout), quads instead of octs as the fp16 candidate group
+    form = (target * 7 + i) % 6
+    idx = vdbhip.FlatIndex(d, metric, [0, 0, 0] if form == 1 else [0, 0] if form == 4 else 0)
+    if form in (2, 4):
+        idx.set_option("int8_only", 1)
+    if form == 3:
+        idx.set_option("f16_group", 4)
     idx.add(X, id_base=11)
     D, I = idx.search(Q, k)
     Do, Io = oracle.knn(X, Q, k, metric, id_base=11)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
+    if form in (2, 4) and kind in ("bytes", "sbytes", "ints") and n > 32768 and d <= 128:
+        assert idx.stats()["has_i8_copy"] == 2
+        Qf = (Q + 0.37).astype(np.float32)          # a non-integer batch on the int8-only index: converted fp16 slabs
+        D, I = idx.search(Qf, k)
+        Do, Io = oracle.knn(X, Qf, k, metric, id_base=11)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
     idx.close()
 
 
@@ -123,10 +138,14 @@ def test_random_ivf_configurations_bit_exact(oracle, i, n, d, nlist, nprobe, nq,
     C = X[rng.choice(n, nlist, replace=False)].copy()
     if i % 4 == 0:
         C[0] = 1e4            # a centroid far from everything: an empty list
-    idx = vdbhip.IVFFlatIndex(d, nlist, metric, 0)
+    idx = vdbhip.IVFFlatIndex(d, nlist, metric, [0, 0] if i % 5 == 1 else 0)       # (round 4: some cases over two shards)
     idx.set_centroids(C)
     if d > 128 and i % 3 == 0:
         idx.set_option("ivf_tps", 64)       # 1024-row spans / 256-row bins instead of the automatic choice
+    if d > 128 and i % 4 == 2:
+        idx.set_option("ivf_group", [4, 2][(i // 4) % 2])      # quads / pairs instead of single rows as the candidate group
+    if d <= 128 and i % 4 == 3:
+        idx.set_option("ivf_i8_group", 8)
     idx.add(X, id_base=3)
     lor = idx.assignment()
     np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, metric))
