@@ -23,8 +23,8 @@ pmc() {    # name, counters..., then -- bench args
   timeout -k 10 240 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $OUT/pmc_$name -o $name -- \
       python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/pmc_$name.log 2>&1 || echo "pmc pass $name failed"
 }
-PHASE=${1:-all}     # all | stats (bench line, kernel stats, breakdowns) | pmc (counter passes, stamps)
-if [ "$PHASE" != "pmc" ]; then
+PHASE=${1:-all}     # all | stats (bench line, kernel stats, breakdowns) | pmc | pmc1 | pmc2 (counter passes, stamps)
+if [ "$PHASE" = "all" ] || [ "$PHASE" = "stats" ]; then
 python3 $R/__graft_entry__.py smoke > $OUT/smoke.txt 2>&1 || echo "smoke failed"
 echo "== bench (driver command)"; date
 timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
@@ -46,6 +46,7 @@ fi   # stats phase
 if [ "$PHASE" != "stats" ]; then
 echo "== PMC passes"; date
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
+if [ "$PHASE" != "pmc2" ]; then      # pmc1: the int8 headline and config 4
 pmc sift1m_sq $SQ1 --
 pmc sift1m_fetch FETCH_SIZE --
 pmc sift1m_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --
@@ -56,13 +57,14 @@ for p in 8 128; do
   pmc ivf${p}_write WRITE_SIZE -- --workload ivf1024 --nprobe $p
   pmc ivf${p}_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- --workload ivf1024 --nprobe $p
 done
+pmc ivf32_fetch FETCH_SIZE -- --workload ivf1024 --nprobe 32
+pmc ivf32_write WRITE_SIZE -- --workload ivf1024 --nprobe 32
+fi
+if [ "$PHASE" != "pmc1" ]; then      # pmc2: the embedding-shaped IVF leg and the real-valued flat scans
 pmc msmarco_sq $SQ1 -- --workload msmarco_ivf
 pmc msmarco_fetch FETCH_SIZE -- --workload msmarco_ivf
 pmc msmarco_write WRITE_SIZE -- --workload msmarco_ivf
 pmc msmarco_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- --workload msmarco_ivf
-pmc ivf32_fetch FETCH_SIZE -- --workload ivf1024 --nprobe 32
-pmc ivf32_write WRITE_SIZE -- --workload ivf1024 --nprobe 32
-# the real-valued flat scans: the same counters as the int8 headline
 for w in gaussian1m glove1.2m; do
   n=${w%%1*}
   pmc ${n}_sq $SQ1 -- --workload $w
@@ -74,6 +76,7 @@ echo "== stamps of the fp16 flat scan (ablations build, scan_variant 6)"; date
 for w in gaussian1m glove1.2m; do
   timeout -k 10 200 python3 $R/scripts/stamp_scan.py $w > $OUT/stamps_$w.txt 2>&1 || echo "stamps $w failed"
 done
+fi
 cd $R
 fi   # pmc phase
 cd $R
@@ -81,7 +84,7 @@ for n in sift1m ivf8 ivf32 ivf128 msmarco gaussian glove; do
   mkdir -p $OUT/pmcsum_$n
   cp $OUT/pmc_${n}_*/*/*counter_collection.csv $OUT/pmcsum_$n/ 2>/dev/null || find $OUT -path "*pmc_${n}_*" -name "*counter_collection.csv" -exec cp --backup=numbered {} $OUT/pmcsum_$n/ \;
 done
-python3 scripts/pmc_summarize_r03.py $OUT > $OUT/pmc_summary.txt 2>&1
+python3 scripts/pmc_summarize_r03.py $OUT > $OUT/pmc_summary_$PHASE.txt 2>&1
 rm -rf $OUT/sift1m $OUT/ivf8 $OUT/ivf32 $OUT/ivf128 $OUT/msmarco_ivf $OUT/gaussian1m $OUT/glove $OUT/marco
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT; ls $OUT
