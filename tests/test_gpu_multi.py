@@ -62,6 +62,11 @@ def test_flat_multi_equals_single_and_oracle(vdb, oracle, metric, shape):
     assert st["ntotal"] == n and st["bytes_resident"] > 0
     if kind == "sift":
         assert st["has_i8_copy"] == 1 and st["scan_dtype"] == 1 and st["last_path_name"] == "mfma_scan"
+    # the remote-shard code path (own query copy, own packed buffer, peer copy into the gather slot) on this one-GPU box
+    multi.set_option("multi_stage_all", 1)
+    D2, I2 = multi.search(Q, k)
+    np.testing.assert_array_equal(I2, Io)
+    np.testing.assert_array_equal(D2, Do)
     # a single query and a second batch through the same buffers
     D1, I1 = multi.search(Q[:1], k)
     np.testing.assert_array_equal(I1, Io[:1])
@@ -127,8 +132,10 @@ def test_device_pointer_entry_points_and_partials(vdb, oracle):
     Do, Io = oracle.knn(X, Q, k, "ip")
     np.testing.assert_array_equal(Id.cpu().numpy(), Io)
     np.testing.assert_array_equal(Dd.cpu().numpy(), Do)
-    # a serving loop through the same buffers: queries rewritten in place
-    for r in range(3):
+    # a serving loop through the same buffers: queries rewritten in place (second half: every shard on the remote-shard path)
+    for r in range(4):
+        if r == 2:
+            a.set_option("multi_stage_all", 1)
         Qd.copy_(torch.from_numpy(np.roll(Q, r + 1, axis=0)).to(dev))
         a.search_device(Qd.data_ptr(), len(Q), k, Dd.data_ptr(), Id.data_ptr(), st)
         torch.cuda.synchronize()
