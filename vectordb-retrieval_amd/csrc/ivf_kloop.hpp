@@ -128,11 +128,12 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
     unsigned idmask = kQuadIdMask;
     asm volatile("" : "+v"(idmask));
     constexpr int NM = kIvfKloopMinima;
-    float m[NM][CB];           // m[0] <= m[1] <= ... : sorted insertion by one v_min + (NM - 1) v_med3 per quad
+    // The running minima of the current bins live in LDS between passes and are in registers only inside the epilogue: with
+    // 128 accumulators, 32 + 32 fragment registers and these 20 the K-loop spilled (256 VGPRs, 20 spilled, 84 bytes of
+    // scratch per lane: kernel-resource-usage of round 4's first build); 40 ds_read / ds_write per pass of 384 MFMAs are free.
+    __shared__ float s_min[NWAVES][NM * CB][64];
 #pragma unroll
-    for (int i = 0; i < NM; ++i)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) m[i][cb] = INF;
+    for (int i = 0; i < NM * CB; ++i) s_min[wave][i][lane] = INF;
 
     float4v acc[HT][CB];
     half8 bq[CB][2];          // B fragments of the current K-step, reloaded in place (see scan_kloop_kernel)
@@ -194,6 +195,11 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                 if (grp == 1) load_b(kn, 0);
             }
         }
+        float m[NM][CB];           // m[0] <= m[1] <= ... : sorted insertion by one v_min + (NM - 1) v_med3 per group
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) m[i][cb] = s_min[wave][i * CB + cb][lane];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             const unsigned id = (unsigned)(slice * HT + t);  // tile number inside the span = quad number inside the bin
@@ -228,6 +234,10 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) s_min[wave][i * CB + cb][lane] = m[i][cb];
     }
 }
 
