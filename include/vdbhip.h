@@ -254,6 +254,7 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       (1024-row spans, 256-row bins) of the p16 panel space
  *     "ivf_group"       D > 128, 64-row bins: rows per candidate group of the list scan, 0 auto | 1 | 2 | 4 (smaller groups cost
  *                       select instructions in the scan and save gathered rows in the exact refine)
+ *     "ivf_tile"        D > 128, 256-row spans: workgroup tile of the list scan, 0 auto / 2 = 256 rows x 256 query slots | 1 = 128 x 512
  *     "ivf_part"        0 auto | spans (256 rows) per row part of the IVF list scan: long lists are cut into parts
  *                       scanned by one workgroup each (rounded up to a multiple of 4 bins)
  *     "select_variant"  0..2;  "spans_per_chunk", "kloop_qgroup": grid shaping of the flat scans

@@ -49,10 +49,24 @@ constexpr int kIvfKloopGroup = 512;     // query slots per work item
 // 2 / 1 = pairs / single rows (TPS = 16 only: 32 / 64 ids per 64-row bin).  Smaller groups cost select instructions here
 // (one sorted insertion per group: 9 -> 14 -> 24 vector ops per quad of scores) and save gathered rows in the refine, which
 // is bound by exactly that gather: 90 -> 47 -> 26 rows of 1.5 KB per query on the msmarco-shaped leg.
-template <int TPS, int BS, int GROUP = 4>
+// RH = row halves of the workgroup tile (round 4).  RH = 1 (default): 128 rows x 512 slots per pass, every wave owns 64 slots.
+// RH = 2 (TPS = 16 only, option "ivf_tile" = 2): **256 rows x 256 slots** -- waves w and w + 4 share 64 slots and take the lower /
+// upper 8 tiles of the span; the upper half hands its five minima over through LDS at the end of the span (one pass = one span)
+// and the lower half merges and stores.  Why it was built: the scan is not bound by the matrix pipe (PMC: 21 % busy) but by
+// the bytes it pulls through the fabric -- per list A x (slots / tile slots) + B x (rows / tile rows) = 0.77 MB x 6.25 + 2.4 MB x
+// 7.8 = 23.6 MB with 128 x 512 tiles, 2.5 GB per msmarco-shaped batch (PMC: 2.53 GB of FETCH_SIZE per launch, 5 TB/s) -- and a
+// square tile of the same accumulator budget moves 19 MB with 4 % instead of 12 % slot padding.  What the A/B said
+// (profiles/r04_sweeps.txt): 0.516 vs 0.499 ms -- no gain.  The two waves of a slot group both gather the B fragments (the
+// second from L2), so the per-CU request rate is unchanged, and that, not the fabric byte count, is the limit: 2.45 GB of
+// gathered 64-byte segments + 1 GB of panel rows per 0.5 ms are 27 GB/s per CU against the 33.5 GB/s per CU a pure
+// Infinity-Cache gather reaches on this chip (MI355X_MICROARCH.md, "Indexed rows").  The form stays as a tested option.
+template <int TPS, int BS, int GROUP = 4, int RH = 1>
 __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) {
     static_assert(GROUP == 4 || ((GROUP == 2 || GROUP == 1) && TPS == 16), "pairs / rows need the 64-row bins of TPS = 16");
-    constexpr int NWAVES = 8, RING = 2 * BS, HT = 8, CB = 4;
+    static_assert(RH == 1 || (RH == 2 && TPS == 16), "the square tile covers one 256-row span per pass");
+    constexpr int NWAVES = 8, RING = 2 * BS, HTW = 8, HT = HTW * RH, CB = 4;
+    constexpr int CG = NWAVES / RH;                          // slot groups of 64 per work item
+    constexpr int kSlots = 64 * CG;                          // query slots per work item (512 or 256)
     constexpr int PPS = TPS / HT;                            // passes per span
     constexpr int SPANROWS = TPS * 16, BINROWS = TPS * 4;
     static_assert(TPS % HT == 0 && TPS <= 64, "the tile number must fit the 6-bit id");
@@ -75,7 +89,8 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int KS = a.ksteps / 2, nK = KS / 2;                // 32-dim k-steps; 64-dim K-steps
-    const int slot0 = a.item_slot0[it] + wave * 64;
+    const int rh = RH == 1 ? 0 : wave / CG, cg = RH == 1 ? wave : wave % CG;      // row half, slot group
+    const int slot0 = a.item_slot0[it] + cg * 64;
     const size_t bin_base = (size_t)a.item_bin0[it];
     const float cs = a.info->cs;
 
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
         for (int step = 0; step < nsteps; ++step) {
             stage_issue(step + BS < nsteps ? step + BS : nsteps - 1, (step + BS) % RING);
             if (BS == 1 || (step % BS) == BS - 1) __syncthreads();
+            if (RH == 2 && (step % nK) == nK - 1) __syncthreads();       // (the hand-over barrier of every pass)
         }
         return;
     }
@@ -131,11 +147,14 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
     // The running minima of the current bins live in LDS between passes and are in registers only inside the epilogue: with
     // 128 accumulators, 32 + 32 fragment registers and these 20 the K-loop spilled (256 VGPRs, 20 spilled, 84 bytes of
     // scratch per lane: kernel-resource-usage of round 4's first build); 40 ds_read / ds_write per pass of 384 MFMAs are free.
-    __shared__ float s_min[NWAVES][NM * CB][64];
+    // (RH = 2: one pass completes its span, nothing persists -- the array is the hand-over buffer of the upper row half)
+    __shared__ float s_min[RH == 1 ? NWAVES : CG][NM * CB][64];
+    if (RH == 1) {
 #pragma unroll
-    for (int i = 0; i < NM * CB; ++i) s_min[wave][i][lane] = INF;
+        for (int i = 0; i < NM * CB; ++i) s_min[wave][i][lane] = INF;
+    }
 
-    float4v acc[HT][CB];
+    float4v acc[HTW][CB];
     half8 bq[CB][2];          // B fragments of the current K-step, reloaded in place (see scan_kloop_kernel)
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.qrows), 0, 0x7fffffff, 0x00020000);
     auto load_b = [&](int kk, int ks) {
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
     auto read_group = [&](int buf, int grp, half8(&dst)[4]) {   // group grp = (ks = grp>>1, tiles 4*(grp&1)..+3)
         const half8 *A = lds_a(buf);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dst[t] = A[(((grp & 1) * 4 + t) * 2 + (grp >> 1)) * 64 + lane];
+        for (int t = 0; t < 4; ++t) dst[t] = A[((rh * HTW + (grp & 1) * 4 + t) * 2 + (grp >> 1)) * 64 + lane];
     };
     read_group(0, 0, fr[0]);
 
@@ -160,8 +179,8 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
         const int slice = pass % PPS;
         // accumulators start from the bias of their rows: local row = BINROWS * g + 4 * (HT * slice + t) + i
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const float4 c = *reinterpret_cast<const float4 *>(a.bias + span * SPANROWS + g * BINROWS + (slice * HT + t) * 4);
+        for (int t = 0; t < HTW; ++t) {
+            const float4 c = *reinterpret_cast<const float4 *>(a.bias + span * SPANROWS + g * BINROWS + (slice * HT + rh * HTW + t) * 4);
             acc[t][0][0] = (c.x >= 0.9e38f) ? kPadBias : c.x * cs;
             acc[t][0][1] = (c.y >= 0.9e38f) ? kPadBias : c.y * cs;
             acc[t][0][2] = (c.z >= 0.9e38f) ? kPadBias : c.z * cs;
@@ -199,10 +218,10 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
 #pragma unroll
         for (int i = 0; i < NM; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) m[i][cb] = s_min[wave][i * CB + cb][lane];
+            for (int cb = 0; cb < CB; ++cb) m[i][cb] = RH == 1 ? s_min[wave][i * CB + cb][lane] : INF;
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const unsigned id = (unsigned)(slice * HT + t);  // tile number inside the span = quad number inside the bin
+        for (int t = 0; t < HTW; ++t) {
+            const unsigned id = (unsigned)(slice * HT + rh * HTW + t);  // tile number inside the span = quad number inside the bin
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 auto insert = [&](float v) {
@@ -222,10 +241,30 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                 }
             }
         }
-        if (slice == PPS - 1) {                              // the four bins (span, g) are complete: [item][slot][bin]
+        if (RH == 2) {      // hand-over: the upper row half's minima of the same bins reach the lower half through LDS
+            if (rh == 1) {
+#pragma unroll
+                for (int i = 0; i < NM; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) s_min[cg][i * CB + cb][lane] = m[i][cb];
+            }
+            __syncthreads();
+            if (rh == 0) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int j = 0; j < NM; ++j) {
+                        const float v = s_min[cg][j * CB + cb][lane];
+#pragma unroll
+                        for (int i = NM - 1; i > 0; --i) m[i][cb] = __builtin_amdgcn_fmed3f(m[i - 1][cb], m[i][cb], v);
+                        m[0][cb] = fast_min(m[0][cb], v, NEG_INF);
+                    }
+            }
+        }
+        if (slice == PPS - 1 && rh == 0) {                   // the four bins (span, g) are complete: [item][slot][bin]
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const size_t o = bin_base * kIvfKloopGroup + (size_t)(wave * 64 + cb * 16 + (lane & 15)) * nb_item +
+                const size_t o = bin_base * kSlots + (size_t)(cg * 64 + cb * 16 + (lane & 15)) * nb_item +
                                  (size_t)((span - lspan0) * 4 + g);
 #pragma unroll
                 for (int i = 0; i < NM; ++i) {
@@ -234,10 +273,12 @@ __global__ __launch_bounds__(512, 2) void ivf_kloop_scan_kernel(IvfKloopArgs a) 
                 }
             }
         }
+        if (RH == 1) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i)
+            for (int i = 0; i < NM; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) s_min[wave][i * CB + cb][lane] = m[i][cb];
+                for (int cb = 0; cb < CB; ++cb) s_min[wave][i * CB + cb][lane] = m[i][cb];
+        }
     }
 }
 

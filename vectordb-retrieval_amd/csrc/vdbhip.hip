@@ -188,6 +188,7 @@ struct vdb_index_s {
     int ivf_bt = 0;                          // option "ivf_bt": tiles per level-1 bin of the IVF scan (0 auto, 4, 16)
     int ivf_part = 0;                        // option "ivf_part": spans per row part of the IVF list scan (0 auto)
     int ivf_min_batch = 1;                   // option "ivf_min_batch": smallest query batch the list-major MFMA scan serves
+    int ivf_tile = 0;                        // option "ivf_tile": workgroup tile of the D > 128 list scan on 256-row spans (0 / 2 square, 1 = 128 x 512)
     int ivf_i8_group = 4;                    // option "ivf_i8_group": rows per candidate group of the int8 list scan (4 | 8)
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
@@ -1213,6 +1214,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "ivf_min_batch") {
             if (value < 1 || value > 1e9) throw Error(VDB_ERR_INVALID, "ivf_min_batch must be >= 1");
             h->ivf_min_batch = (int)value;
+        } else if (k == "ivf_tile") {
+            if (value != 0 && value != 1 && value != 2) throw Error(VDB_ERR_INVALID, "ivf_tile must be 0, 1 or 2");
+            h->ivf_tile = (int)value;
         } else if (k == "ivf_i8_group") {
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "ivf_i8_group must be 4 or 8");
             h->ivf_i8_group = (int)value;
