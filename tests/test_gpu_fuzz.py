@@ -147,6 +147,8 @@ def test_random_ivf_configurations_bit_exact(oracle, i, n, d, nlist, nprobe, nq,
         idx.set_option("ivf_group", [4, 2][(i // 4) % 2])      # quads / pairs instead of single rows as the candidate group
     if d <= 128 and i % 4 == 3:
         idx.set_option("ivf_i8_group", 8)
+    if d > 128 and i % 2 == 1:
+        idx.set_option("ivf_tile", 2)           # the square workgroup tile of the K-loop list scan (hand-over of minima through LDS)
     idx.add(X, id_base=3)
     lor = idx.assignment()
     np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, metric))

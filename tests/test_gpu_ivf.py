@@ -419,6 +419,20 @@ def test_kloop_list_scan_bit_exact(vdb, oracle, n, d, nlist, nq, k, metric, tps,
         np.testing.assert_array_equal(I2, I, err_msg=f"ivf_part={part}")
         np.testing.assert_array_equal(D2, D, err_msg=f"ivf_part={part}")
     idx.set_option("ivf_part", 0)
+    # round 4: every candidate group (rows / pairs / quads on 64-row bins) and both workgroup tiles give the same result
+    for opt, values in (("ivf_group", (4, 2, 1, 0)), ("ivf_tile", (2, 0))):
+        for v in values:
+            idx.set_option(opt, v)
+            D3, I3 = idx.search(Q, k)
+            np.testing.assert_array_equal(I3, I, err_msg=f"{opt}={v}")
+            np.testing.assert_array_equal(D3, D, err_msg=f"{opt}={v}")
+    idx.set_option("ivf_tile", 2)
+    idx.set_option("ivf_group", 2)
+    D3, I3 = idx.search(Q[:130], k)            # (square tile + pairs, a batch that leaves waves without slots)
+    np.testing.assert_array_equal(I3, Io[:130])
+    np.testing.assert_array_equal(D3, Do[:130])
+    idx.set_option("ivf_tile", 0)
+    idx.set_option("ivf_group", 0)
     # small batches (one partly filled work item per list) and a forced overflow of every work list
     for nqs in (1, 7, 70):
         Ds, Is = idx.search(Q[:nqs], k)
