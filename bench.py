@@ -579,9 +579,10 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None, traffic_key=None):
     if traffic and scan_ms > 0:     # what the recorded traffic amounts to at THIS run's kernel time (fabric-side bytes: HBM + Infinity Cache)
         rate = traffic / (scan_ms * 1e-3) / 1e12
         memory_side = {"traffic_tb_s": round(rate, 2), "traffic_over_hbm_peak": round(rate / (HBM_PEAK_GBS / 1000.0), 3)}
-        if ivf_rows_probed is not None and d > 128:
-            # the K-loop list scan gathers its B fragments (64-byte segments of the query rows) per K-step and re-reads list panels
-            # per slot group, all from the Infinity Cache: its binding resource is that gather rate, not the matrix pipe
+        if ivf_rows_probed is not None:
+            # the list-major scans gather their B fragments (64-byte segments of the query rows: per K-step for D > 128, per work
+            # item for D <= 128) and re-read list panels per slot group, all from the Infinity Cache: at nprobe 32 / 128 their
+            # binding resource is that gather rate, not the matrix pipe (PMC: 5.0 - 5.3 TB/s fabric-side at both widths)
             memory_side["second_bound"] = {"bound": "infinity-cache gather", "achieved": round(rate, 2), "peak": 8.6, "unit": "TB/s",
                                            "frac": round(rate / 8.6, 3),
                                            "note": "peak = gathered rows from an Infinity-Cache-resident table, MI355X_MICROARCH.md "

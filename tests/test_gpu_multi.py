@@ -271,3 +271,23 @@ def test_harness_drives_a_sharded_yaml_entry():
         json.dumps(m)
     assert res["exact_2gpu"]["parameters"]["device_ids"] == [0, 0]
     assert res["exact_2gpu"]["index_memory_mb"] > 0
+
+
+def test_ivf_shards_without_rows(vdb, oracle):
+    """Fewer rows than shards: blocks of 2 / 2 / 1 / 0 rows -- an IVF shard with nothing filed answers with padding only."""
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((5, 8)).astype(np.float32)
+    Q = rng.standard_normal((3, 8)).astype(np.float32)
+    C = X[:2].copy()
+    ix = vdb.IVFFlatIndex(8, 2, "l2", [0, 0, 0, 0])
+    ix.set_centroids(C)
+    ix.add(X, id_base=100)
+    lor = ix.assignment()
+    np.testing.assert_array_equal(lor, oracle.ivf_assign(C, X, "l2"))
+    for nprobe, k in ((2, 7), (1, 2)):
+        ix.set_nprobe(nprobe)
+        D, I = ix.search(Q, k)
+        Do, Io = oracle.ivf_search(X, C, lor, Q, k, nprobe, "l2", id_base=100)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+    ix.close()
