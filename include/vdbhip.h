@@ -108,8 +108,8 @@ int vdb_create(int dim, int metric, int device, vdb_handle *out);
  *   vdb_ivf_train  runs k-means once (on devices[0], over the whole training set); every shard files its rows under the same
  *                  centroids and probes the same lists;
  *   vdb_reserve, vdb_stats (sums / maxima over the shards, ndevices), vdb_set_option (forwarded), vdb_reset, vdb_destroy,
- *   vdb_ivf_set_centroids / _get_centroids / _set_nprobe / _get_assignment  work as on one device.
- * Not available on such a handle (VDB_ERR_UNSUPPORTED): vdb_rerank(_device), option "graph", the debug hooks.
+ *   vdb_ivf_set_centroids / _get_centroids / _set_nprobe / _get_assignment, vdb_rerank(_device)  work as on one device.
+ * Not available on such a handle (VDB_ERR_UNSUPPORTED): option "graph", the debug hooks.
  * Option "multi_stage_all" = 1 (tests) makes shards on devices[0] take the remote-shard path too (own query copy, packed buffer,
  * peer copy), so a one-GPU box exercises the code a multi-GPU node runs.
  * A device may be listed more than once (several shards on one GPU). */

@@ -199,8 +199,6 @@ def test_what_a_multi_handle_refuses(vdb):
     m = vdb.FlatIndex(16, "l2", [0, 0])
     m.add(X)
     with pytest.raises(RuntimeError, match="multi-device"):
-        m.rerank(Q, np.zeros((4, 3), np.int64), 2)
-    with pytest.raises(RuntimeError, match="multi-device"):
         m.set_option("graph", 1)
     m.set_option("force_path", 1)                        # forwarded to every shard
     m.search(Q, 3)
@@ -291,3 +289,39 @@ def test_ivf_shards_without_rows(vdb, oracle):
         np.testing.assert_array_equal(I, Io)
         np.testing.assert_array_equal(D, Do)
     ix.close()
+
+
+def test_candidate_rerank_on_a_multi_device_handle(vdb, oracle):
+    """vdb_rerank on shards: global candidate ids are mapped to each shard's rows through its segment triples (appends
+    included), partial lists merged -- equal to the single-device index."""
+    import torch
+
+    X, Q = _gauss(30_000, 40, 33, 17)
+    multi = vdb.FlatIndex(40, "l2", [0, 0, 0])
+    single = vdb.FlatIndex(40, "l2", 0)
+    for a, b in ((0, 12_001), (12_001, 30_000)):            # two adds: every shard holds two id ranges
+        multi.add(X[a:b], id_base=50)
+        single.add(X[a:b], id_base=50)
+    rng = np.random.default_rng(2)
+    cand = np.stack([rng.choice(30_000, 64, replace=False) for _ in range(len(Q))]).astype(np.int64) + 50
+    cand[:, 60:] = -1                                        # empty slots
+    cand[0, :5] = [10, 49, 30_050 + 7, 10 ** 9, 50]          # ids outside the index (50 = row 0 is inside)
+    for k in (1, 10, 64):
+        Dm, Im = multi.rerank(Q, cand, k)
+        Ds, Is = single.rerank(Q, cand, k)
+        np.testing.assert_array_equal(Im, Is)
+        np.testing.assert_array_equal(Dm, Ds)
+    multi.set_option("multi_stage_all", 1)
+    np.testing.assert_array_equal(multi.rerank(Q, cand, 10)[1], single.rerank(Q, cand, 10)[1])
+    # device pointers
+    from vdbhip import _ffi
+    dev = torch.device("cuda", 0)
+    qd, cd = torch.from_numpy(Q).to(dev), torch.from_numpy(cand).to(dev)
+    Dd = torch.empty((len(Q), 10), dtype=torch.float32, device=dev)
+    Id = torch.empty((len(Q), 10), dtype=torch.int64, device=dev)
+    _ffi.check(_ffi.load().vdb_rerank_device(multi._handle(), qd.data_ptr(), len(Q), cd.data_ptr(), cand.shape[1], 10,
+                                             Dd.data_ptr(), Id.data_ptr(), torch.cuda.current_stream().cuda_stream or None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(Id.cpu().numpy(), single.rerank(Q, cand, 10)[1])
+    multi.close()
+    single.close()

@@ -391,8 +391,14 @@ struct RerankArgs {
     int64_t nq;
     const int64_t *cand;   // [nq][ncand] ids (id_base + row), -1 = empty
     int ncand;
-    float *D;
+    float *D;              // final rows, or (D == nullptr) partial rows: float64 keys + ids
     int64_t *I;
+    double *pkeys = nullptr;
+    int64_t *pids = nullptr;
+    // a shard of a multi-device index (multi.inc): candidate ids are GLOBAL; this shard holds the id ranges
+    // [segs[3j], segs[3j] + segs[3j + 2]) as its local rows segs[3j + 1] ..., every other id is not ours (nullptr: row = id - id_base)
+    const int64_t *segs = nullptr;
+    int nseg = 0;
 };
 
 template <int KPL>
@@ -408,14 +414,22 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
         const int i = base + lane;
         bool valid = i < a.ncand;
         const int64_t id = valid ? cr[i] : -1;
-        const int64_t row = id - a.c.id_base;
+        int64_t row = id - a.c.id_base;
+        if (a.segs) {
+            row = -1;
+            for (int j = 0; j < a.nseg; ++j) {
+                const int64_t id0 = a.segs[3 * j];
+                if (id >= id0 && id < id0 + a.segs[3 * j + 2]) row = a.segs[3 * j + 1] + (id - id0);
+            }
+        }
         valid = valid && id >= 0 && row >= 0 && row < a.c.N;
         uint64_t key = ~0ull;
         if (valid) key = row_key(a.c, row, qptr);
         tk.offer(key, id, valid);
     }
     const size_t o = (size_t)q * a.c.k;
-    write_topk<KPL>(tk, a.c.metric, a.D + o, a.I + o, nullptr, nullptr);
+    write_topk<KPL>(tk, a.c.metric, a.D ? a.D + o : nullptr, a.I ? a.I + o : nullptr, a.pkeys ? a.pkeys + o : nullptr,
+                    a.pids ? a.pids + o : nullptr);
 }
 
 // ---- exhaustive mode: every row of the shard, split over S waves per query -----------------------

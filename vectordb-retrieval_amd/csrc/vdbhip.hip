@@ -763,6 +763,8 @@ void multi_set_option(vdb_index_s *m, const char *key, double value);
 void multi_set_centroids(vdb_index_s *m, const float *c_host, int nlist);
 void multi_train(vdb_index_s *m, int nlist, const float *x_host, int64_t n, int niter, uint64_t seed, int mppc);
 void multi_get_assignment(vdb_index_s *m, int32_t *out);
+void multi_rerank(vdb_index_s *m, const float *q, bool device_api, int64_t nq, const int64_t *cand, int ncand, int k, float *D,
+                  int64_t *I, hipStream_t user_stream);
 vdb_index_s *multi_first_shard(vdb_index_s *m);
 void multi_for_each_shard(vdb_index_s *m, const std::function<void(vdb_index_s *)> &f);
 [[noreturn]] inline void multi_unsupported(const char *what) {
@@ -987,13 +989,15 @@ int vdb_merge_packed_partials_device(int metric, int device, const void *packed_
 }
 
 namespace {
+// (pk / pi: partial rows -- float64 keys + ids -- instead of (D, I); segs / nseg: a shard of a multi-device index, see RerankArgs)
 void rerank_device_impl(vdb_index_s *h, const float *dq, int64_t nq, const int64_t *cand, int ncand, int k, float *D,
-                        int64_t *I, hipStream_t st) {
+                        int64_t *I, hipStream_t st, double *pk = nullptr, int64_t *pi = nullptr, const int64_t *segs = nullptr,
+                        int nseg = 0) {
     if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
     if (k < 1 || k > 2048) throw Error(VDB_ERR_INVALID, "k must be in [1, 2048]");
     if (nq < 0 || ncand < 0) throw Error(VDB_ERR_INVALID, "negative size");
     if (nq == 0) return;
-    if (!dq || !D || !I || (ncand > 0 && !cand)) throw Error(VDB_ERR_INVALID, "null pointer");
+    if (!dq || (pk ? !pi : (!D || !I)) || (ncand > 0 && !cand)) throw Error(VDB_ERR_INVALID, "null pointer");
     const float *qpad = dq;
     if (h->D4 != h->dim) {
         h->ws.qpad.reserve((size_t)nq * h->D4 * sizeof(float));
@@ -1011,8 +1015,12 @@ void rerank_device_impl(vdb_index_s *h, const float *dq, int64_t nq, const int64
     a.nq = nq;
     a.cand = cand;
     a.ncand = ncand;
-    a.D = D;
-    a.I = I;
+    a.D = pk ? nullptr : D;
+    a.I = pk ? nullptr : I;
+    a.pkeys = pk;
+    a.pids = pi;
+    a.segs = segs;
+    a.nseg = nseg;
     const int kpl = kpl_for(k);
     DISPATCH_KPL(kpl, (rerank_kernel<KPL><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st>>>(a)));
     VDB_HIP(hipGetLastError());
@@ -1023,7 +1031,7 @@ int vdb_rerank_device(vdb_handle hh, const float *q_dev, int64_t nq, const int64
                       float *D_dev, int64_t *I_dev, void *stream) {
     return guarded([&] {
         auto *h = check(hh);
-        if (h->multi) multi_unsupported("vdb_rerank_device");
+        if (h->multi) return multi_rerank(h, q_dev, true, nq, cand_dev, ncand, k, D_dev, I_dev, as_stream(stream));
         set_device(h->device);
         rerank_device_impl(h, q_dev, nq, cand_dev, ncand, k, D_dev, I_dev, as_stream(stream));
     });
@@ -1033,7 +1041,7 @@ int vdb_rerank(vdb_handle hh, const float *q_host, int64_t nq, const int64_t *ca
                int64_t *I) {
     return guarded([&] {
         auto *h = check(hh);
-        if (h->multi) multi_unsupported("vdb_rerank");
+        if (h->multi) return multi_rerank(h, q_host, false, nq, cand_host, ncand, k, D, I, nullptr);
         if (!h->built) throw Error(VDB_ERR_STATE, "Index has not been built yet.");
         if (nq <= 0) {
             if (nq < 0) throw Error(VDB_ERR_INVALID, "negative query count");
