@@ -205,77 +205,18 @@ __global__ __launch_bounds__(64) void dense_select_kernel(DenseSelectArgs a) {
     }
 }
 
-// Same selection for Npad <= 64 * VPL rows (IVF coarse quantizers with nlist <= 2048), with the query's scores held
-// in REGISTERS (row e*64 + lane in v[e]) and a cheaper threshold.  The LDS form above bisects for the exact k-th smallest
-// score tau: 32 passes over all Npad scores, LDS-bandwidth bound (100 us per 10k queries on 1024 centroids); doing the
-// same passes on registers with v_cmp + ballot is bound by the CU's one scalar unit instead (58 us).  Any U >= tau is
-// a valid threshold (every true neighbour has an approximate score <= tau + 2 eps <= U + 2 eps), so here every lane
-// first keeps the M smallest of its VPL scores and U = the k-th smallest of those 64*M values (they are distinct rows,
-// so U >= tau; equal to tau unless more than M of the k best fall on one lane).  The bisection then costs M compares
-// per step instead of VPL, and the few extra rows U lets through are re-scored in lanes that would idle anyway.
-// 4 queries per workgroup; LDS holds only the candidate lists.
-template <int KPL, int VPL>
-__global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_select_reg_kernel(DenseSelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
-    constexpr int M = KPL <= 1 ? 2 : (2 * KPL <= VPL ? 2 * KPL : VPL);     // 64*M >= 2k: k <= 64*KPL
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
-    if (q >= a.nq) return;
-    int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * 2 * a.cand_cap;      // rows | their approximate keys
-    unsigned *ckeys = reinterpret_cast<unsigned *>(cands + a.cand_cap);
-    const int n = (int)(a.ncols > 0 ? a.ncols : a.Npad), k = a.c.k;
-    const float *src = a.scores + (size_t)q * a.Npad;
-    unsigned v[VPL];
-    float sv[VPL];                                  // (all loads in flight before the first use: see select_kernel, scan.hpp)
-#pragma unroll
-    for (int e = 0; e < VPL; ++e) sv[e] = src[min(e * 64 + lane, n - 1)];
-#pragma unroll
-    for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sv[e]));
-#pragma unroll
-    for (int e = 0; e < VPL; ++e) v[e] = (e * 64 + lane < n) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
-    unsigned low[M];                                // the M smallest of this lane, ascending
-#pragma unroll
-    for (int j = 0; j < M; ++j) low[j] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int e = 0; e < VPL; ++e) {
-        unsigned x = v[e];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const unsigned t = min(low[j], x);
-            x = max(low[j], x);
-            low[j] = t;
-        }
-    }
-    unsigned ans = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned trial = ans | ((1u << bit) - 1u);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < M; ++j) cnt += __popcll(__ballot(low[j] <= trial));
-        if (cnt < k) ans |= (1u << bit);
-    }
-    const float e2 = 2.0f * a.eps[q];
-    const float that = unsortable_f32(ans) + e2;
-    bool fb = a.info->force_fallback || !(that < 0.9e38f);
-    const unsigned tkey = sortable_u32(that);
+// Everything behind the candidate list of one query, wave-wide (64 lanes on ONE query): overflow / unusable scales -> exhaustive
+// scan; set-only mode -> certain rows written as they are, the band around the k-th key re-scored; else exact re-scoring of all
+// candidates.  (Round 4 tried a form of dense_select_reg_kernel with 2 / 4 queries per wave -- 32 / 16 lanes per query, counts
+// reduced inside the lane group, this tail only for queries its shortcut did not settle: 13 - 23 us SLOWER per coarse search,
+// profiles/r04_sweeps.txt.  The bisection needs LPQ x M >= 2k lane minima, so fewer lanes per query mean proportionally more
+// compares and ballots per step: the instruction count per query does not fall.  Removed; the tail stayed a function.)
+template <int KPL>
+__device__ __forceinline__ void dense_select_tail(const DenseSelectArgs &a, int64_t q, int *cands, unsigned *ckeys, int ncand, bool fb,
+                                                  unsigned ans, float e2) {
+    const int lane = threadIdx.x & 63;
+    const int k = a.c.k;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int ncand = 0;
-    if (!fb) {
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            const int i = e * 64 + lane;
-            const bool hit = i < n && v[e] <= tkey;
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int pos = ncand + __popcll(m & lt_mask);
-                if (pos < a.cand_cap) {
-                    cands[pos] = i;
-                    ckeys[pos] = v[e];
-                }
-            }
-            ncand += __popcll(m);
-        }
-    }
     if (ncand > a.cand_cap) fb = true;
     if (fb) {
         if (a.inline_fallback) {
@@ -393,5 +334,80 @@ __global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_
         stat_add(a.stat_counters, q, 0, (unsigned long long)ncand);
     }
 }
+
+// Same selection for Npad <= 64 * VPL rows (IVF coarse quantizers with nlist <= 2048), with the query's scores held
+// in REGISTERS (row e*64 + lane in v[e]) and a cheaper threshold.  The LDS form above bisects for the exact k-th smallest
+// score tau: 32 passes over all Npad scores, LDS-bandwidth bound (100 us per 10k queries on 1024 centroids); doing the
+// same passes on registers with v_cmp + ballot is bound by the CU's one scalar unit instead (58 us).  Any U >= tau is
+// a valid threshold (every true neighbour has an approximate score <= tau + 2 eps <= U + 2 eps), so here every lane
+// first keeps the M smallest of its VPL scores and U = the k-th smallest of those 64*M values (they are distinct rows,
+// so U >= tau; equal to tau unless more than M of the k best fall on one lane).  The bisection then costs M compares
+// per step instead of VPL, and the few extra rows U lets through are re-scored in lanes that would idle anyway.
+// 4 queries per workgroup; LDS holds only the candidate lists.
+template <int KPL, int VPL>
+__global__ __launch_bounds__(256, ((KPL <= 2 && VPL <= 16) ? 6 : 4)) void dense_select_reg_kernel(DenseSelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];
+    constexpr int M = KPL <= 1 ? 2 : (2 * KPL <= VPL ? 2 * KPL : VPL);     // 64*M >= 2k: k <= 64*KPL
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    if (q >= a.nq) return;
+    int *cands = reinterpret_cast<int *>(dense_smem) + (size_t)wave * 2 * a.cand_cap;      // rows | their approximate keys
+    unsigned *ckeys = reinterpret_cast<unsigned *>(cands + a.cand_cap);
+    const int n = (int)(a.ncols > 0 ? a.ncols : a.Npad), k = a.c.k;
+    const float *src = a.scores + (size_t)q * a.Npad;
+    unsigned v[VPL];
+    float sv[VPL];                                  // (all loads in flight before the first use: see select_kernel, scan.hpp)
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) sv[e] = src[min(e * 64 + lane, n - 1)];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) asm volatile("" : "+v"(sv[e]));
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) v[e] = (e * 64 + lane < n) ? sortable_u32(sv[e]) : 0xFFFFFFFFu;
+    unsigned low[M];                                // the M smallest of this lane, ascending
+#pragma unroll
+    for (int j = 0; j < M; ++j) low[j] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+        unsigned x = v[e];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const unsigned t = min(low[j], x);
+            x = max(low[j], x);
+            low[j] = t;
+        }
+    }
+    unsigned ans = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = ans | ((1u << bit) - 1u);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) cnt += __popcll(__ballot(low[j] <= trial));
+        if (cnt < k) ans |= (1u << bit);
+    }
+    const float e2 = 2.0f * a.eps[q];
+    const float that = unsortable_f32(ans) + e2;
+    bool fb = a.info->force_fallback || !(that < 0.9e38f);
+    const unsigned tkey = sortable_u32(that);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int ncand = 0;
+    if (!fb) {
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) {
+            const int i = e * 64 + lane;
+            const bool hit = i < n && v[e] <= tkey;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = ncand + __popcll(m & lt_mask);
+                if (pos < a.cand_cap) {
+                    cands[pos] = i;
+                    ckeys[pos] = v[e];
+                }
+            }
+            ncand += __popcll(m);
+        }
+    }
+    dense_select_tail<KPL>(a, q, cands, ckeys, ncand, fb, ans, e2);
+}
+
 
 }  // namespace vdb
