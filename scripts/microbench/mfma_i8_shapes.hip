@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void loop32(const int4v *A, const i
 #pragma unroll
                     for (int g = 0; g < 16 / G; ++g) {
                         int q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
-                        if (G == 8) q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+                        if (G >= 8) q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+                        if (G == 16)     // round 4: one group per (tile, column block) -- 16 rows per candidate group
+                            q = imin(q, imin(imin(imin(acc[cb][8], acc[cb][9]), imin(acc[cb][10], acc[cb][11])),
+                                             imin(imin(acc[cb][12], acc[cb][13]), imin(acc[cb][14], acc[cb][15]))));
                         fold(q, (unsigned)((t * (16 / G) + g) & 63), m1[cb], m2[cb]);
                     }
             } else {
@@ -137,7 +140,10 @@ __global__ __launch_bounds__(512, 2) void loop32s(const int4v *A, const int4v *B
 #pragma unroll
             for (int g = 0; g < 16 / G; ++g) {
                 int q = imin(imin(acc[cb][G * g], acc[cb][G * g + 1]), imin(acc[cb][G * g + 2], acc[cb][G * g + 3]));
-                if (G == 8) q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+                if (G >= 8) q = imin(q, imin(imin(acc[cb][G * g + 4], acc[cb][G * g + 5]), imin(acc[cb][G * g + 6], acc[cb][G * g + 7])));
+                if (G == 16)
+                    q = imin(q, imin(imin(imin(acc[cb][8], acc[cb][9]), imin(acc[cb][10], acc[cb][11])),
+                                     imin(imin(acc[cb][12], acc[cb][13]), imin(acc[cb][14], acc[cb][15]))));
                 fold(q, (unsigned)((t * (16 / G) + g) & 63), m1[cb], m2[cb]);
             }
     };
@@ -335,11 +341,15 @@ int main() {
         R32(4, 2, 1, 8, "octs")   R16(8, 2, 1, 8, "octs")
         R32(4, 1, 0, 4, "bare")   R16(8, 1, 0, 4, "bare")
         R32(4, 1, 1, 8, "octs")   R16(8, 1, 1, 8, "octs")
+        R32(4, 2, 1, 16, "hexadecs")      // round 4: what fewer select instructions per score are worth
 #define R32S(SYNC, label) report("32x32x32", 128, 2, label, run(loop32s<4, SYNC, 8>, 512, dA, dB, dO, dC, nblk, iters, e0, e1));
         R32S(0, "octs, loop32s")
         R32S(1, "octs +barrier/8t")
         R32S(2, "octs +bar +DMA")
         R32S(3, "octs +bar+DMA+stag")
+#define R32S16(SYNC, label) report("32x32x32", 128, 2, label, run(loop32s<4, SYNC, 16>, 512, dA, dB, dO, dC, nblk, iters, e0, e1));
+        R32S16(0, "hexadecs, loop32s")
+        R32S16(3, "hexa +bar+DMA+stag")
     }
     return 0;
 }
