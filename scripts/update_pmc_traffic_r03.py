@@ -15,6 +15,7 @@ WANT = {  # pass group -> (json key, substrings the kernel name must contain)
     "ivf32": ("ivf1024_nprobe32", ("scan_i8_kernel", "true")),
     "gaussian": ("gaussian1m", ("scan_kernel<8",)),
     "glove": ("glove1.2m", ("scan_kernel<4",)),
+    "marco": ("marco12.5m", ("scan16_kloop_kernel",)),
 }
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r03"
 CORR = ("gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced streams (global_load / LDS-DMA alike) -> doubled; "
