@@ -274,6 +274,93 @@ __global__ __launch_bounds__(256 * WPS, WPS) void loop16(const int4v *A, const i
     }
 }
 
+// ---- 16x16x64 with the scan's STAGING (round 4): a tile = 32 rows = two 16-row blocks x two 64-dim fragments, 8 column
+// blocks of 16 queries per wave (128 queries, as loop32s<4>); one oct per (tile, column block) = the lane's 4 rows of both
+// row blocks.  SYNC as loop32s.
+template <int SYNC>
+__global__ __launch_bounds__(512, 2) void loop16s(const int4v *A, const int4v *B, int *out, unsigned long long *clk, int iters) {
+    constexpr int NT = 512, ST = 8, CB = 8, kStage = ST * 4 * 64;
+    __shared__ int4v lds[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * kStage; i += NT) lds[i] = A[i % kLdsVec];
+    int4v b[CB][2];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b[cb][ks] = B[(((wave * CB + cb) * 2 + ks) % 128) * 64 + lane];
+    __syncthreads();
+    int m1[CB], m2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) m1[cb] = m2[cb] = 0x7fffffff;
+    const bool late = SYNC == 3 && wave >= 4;
+    int4v acc[2][CB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[u][cb] = int4v{0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff};
+    auto select = [&](int t) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int t1 = imin(imin(acc[0][cb][0], acc[0][cb][1]), acc[0][cb][2]);
+            const int t2 = imin(imin(acc[0][cb][3], acc[1][cb][0]), acc[1][cb][1]);
+            const int q = imin(imin(imin(acc[1][cb][2], acc[1][cb][3]), t1), t2);
+            fold(q, (unsigned)(t & 63), m1[cb], m2[cb]);
+        }
+    };
+    const Stamp s0 = stamp_now();
+    const int nstage = iters * (kLdsVec / kStage);
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (SYNC >= 2) {
+            const int4v *src = A + ((st + 1) % (kLdsVec / kStage)) * kStage;
+            int4v *dst = lds + (buf ^ 1) * kStage;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wave + i * 8;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(src + p * 64 + lane)),
+                    reinterpret_cast<__attribute__((address_space(3))) void *>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + p * 64))),
+                    16, 0, 0);
+            }
+        }
+        const int4v *base = lds + (SYNC >= 2 ? buf * kStage : 0);
+#pragma unroll 1
+        for (int t = 0; t < ST; ++t) {
+            const int4v c0 = base[(t * 37 + (lane >> 4)) & 1023], c1 = base[(t * 37 + 4 + (lane >> 4)) & 1023];
+            const int4v *a = base + t * 4 * 64 + lane;
+            const int4v f00 = a[0], f01 = a[64], f10 = a[128], f11 = a[192];
+            if (late) {
+                __builtin_amdgcn_sched_barrier(0);
+                select(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f00, b[cb][0], c0, 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f10, b[cb][0], c1, 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f01, b[cb][1], acc[0][cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f11, b[cb][1], acc[1][cb], 0, 0, 0);
+            if (!late) {
+                if (SYNC == 3) __builtin_amdgcn_sched_barrier(0);
+                select(t);
+                if (SYNC == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (SYNC >= 1) __syncthreads();
+    }
+    const Stamp s1 = stamp_now();
+    int r = 0;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) r += m1[cb] + m2[cb] + acc[1][cb][2];
+    out[blockIdx.x * NT + tid] = r;
+    if (lane == 0) {
+        clk[((size_t)blockIdx.x * (NT / 64) + wave) * 2] = s1.cyc - s0.cyc;
+        clk[((size_t)blockIdx.x * (NT / 64) + wave) * 2 + 1] = s1.real - s0.real;
+    }
+}
+
 struct Result { float ms; double cyc, ghz; };
 
 template <class K>
@@ -350,6 +437,11 @@ int main() {
 #define R32S16(SYNC, label) report("32x32x32", 128, 2, label, run(loop32s<4, SYNC, 16>, 512, dA, dB, dO, dC, nblk, iters, e0, e1));
         R32S16(0, "hexadecs, loop32s")
         R32S16(3, "hexa +bar+DMA+stag")
+#define R16S(SYNC, label) report("16x16x64", 128, 2, label, run(loop16s<SYNC>, 512, dA, dB, dO, dC, nblk, iters, e0, e1));
+        R16S(0, "octs, loop16s")
+        R16S(2, "octs +bar +DMA")
+        R16S(3, "octs +bar+DMA+stag")
+        R32S(3, "octs +bar+DMA+stag")       // (again, next to the 16x16x64 rows: same thermal state)
     }
     return 0;
 }

@@ -71,13 +71,15 @@ def test_random_shapes_and_distributions_bit_exact(oracle, target, i, n, d, nq, 
         Q[0] = X[n // 7]
     # round 4: every third case runs on another form of the engine (same results whatever the form): several shards in one
     # handle (vdb_create_multi), an int8-only index (byte-valued corpora of > 32 768 rows take it, the rest fall back to the
-    # default layout), quads instead of octs as the fp16 candidate group
+    # default layout), quads instead of octs as the fp16 candidate group, the 32x32x32 shape of the int8 scan
     form = (target * 7 + i) % 6
     idx = vdbhip.FlatIndex(d, metric, [0, 0, 0] if form == 1 else [0, 0] if form == 4 else 0)
     if form in (2, 4):
         idx.set_option("int8_only", 1)
     if form == 3:
         idx.set_option("f16_group", 4)
+    if form == 5 or (form == 2 and i % 2):
+        idx.set_option("i8_shape", 32)      # the 32x32x32 int8 scan and its panel layout (default: 16x16x64, layout "x16")
     idx.add(X, id_base=11)
     D, I = idx.search(Q, k)
     Do, Io = oracle.knn(X, Q, k, metric, id_base=11)

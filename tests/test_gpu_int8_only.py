@@ -36,7 +36,7 @@ def test_int8_only_equals_default_index_and_oracle(vdb, oracle, metric, n, d, wi
     X = _bytes(n, d, n + d) if window == "u8" else _bytes(n, d, n + d, lo=-128, hi=90)
     Qi = _bytes(300, d, 5) if window == "u8" else _bytes(300, d, 5, lo=-128, hi=90)        # integer queries: int8 scan
     Qf = (Qi + np.random.default_rng(6).standard_normal(Qi.shape).astype(np.float32) * 3).astype(np.float32)   # fp16 slabs
-    ix = _index(vdb, X, metric, int8_block_rows=16_384)         # (several ingestion blocks)
+    ix = _index(vdb, X, metric, int8_block_rows=16_384, i8_shape=32 if d == 64 else 0)   # (several ingestion blocks; one case on the 32x32x32 panels)
     st = ix.stats()
     assert st["has_i8_copy"] == 2 and st["ntotal"] == n
     corpus = X.nbytes

@@ -493,9 +493,11 @@ def _bytes_data(n, d, nq, window, seed, extreme=False):
     (40000, 128, 300, 10, "ip", "s8", True),
     (40000, 128, 300, 10, "l2", "s8", True),
 ])
-def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metric, window, extreme):
+@pytest.mark.parametrize("shape", [16, 32])       # 16: v_mfma_i32_16x16x64_i8 on layout "x16" (default); 32: 32x32x32
+def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metric, window, extreme, shape):
     X, Q = _bytes_data(n, d, nq, window, seed=n + d, extreme=extreme)
     idx = vdb.FlatIndex(d, metric, 0)
+    idx.set_option("i8_shape", shape)
     idx.add(X, id_base=3)
     D, I = idx.search(Q, k)
     st = idx.stats()
@@ -511,7 +513,7 @@ def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metr
     np.testing.assert_array_equal(I1, I)
     np.testing.assert_array_equal(D1, D)
     idx.set_option("panel_dtype", 0)
-    # select on quads (4 rows per candidate) instead of the default octs: same result
+    # select on quads (4 rows per candidate) instead of the default octs: same result (layout "x16" has octs only: no-op there)
     idx.set_option("i8_group", 4)
     D4, I4 = idx.search(Q, k)
     assert idx.stats()["scan_dtype"] == 1
@@ -535,6 +537,40 @@ def test_int8_scan_bit_exact_and_chosen_on_device(vdb, oracle, n, d, nq, k, metr
     np.testing.assert_array_equal(I3, Io3)
     np.testing.assert_array_equal(D3, Do3)
     idx.close()
+
+
+@pytest.mark.parametrize("n,d", [(1_000_000, 64), (700_000, 128)])
+def test_int8_x16_launch_shapes_equal_the_32x32x32_scan(vdb, oracle, n, d):
+    """Every launch shape of the 16x16x64 scan (1024- and 512-query tiles, 4- and 8-tile stages, 1 / 2 / 4-wave serving shapes with
+    their staging rings) against the 32x32x32 scan of the same corpus, bit for bit, and a query sample against the oracle."""
+    X, Q = _bytes_data(n, d, 4096, "u8", seed=d)
+    a = vdb.FlatIndex(d, "l2", 0)
+    a.add(X, id_base=0)
+    b = vdb.FlatIndex(d, "l2", 0)
+    b.set_option("i8_shape", 32)
+    b.add(X, id_base=0)
+    Db, Ib = b.search(Q, 10)
+    assert b.stats()["scan_dtype"] == 1
+    for variant in (3, 2, 1, 0):
+        a.set_option("i8_variant", variant)
+        Da, Ia = a.search(Q, 10)
+        assert a.stats()["scan_dtype"] == 1 and a.stats()["last_path_name"] == "mfma_scan"
+        np.testing.assert_array_equal(Ia, Ib)
+        np.testing.assert_array_equal(Da, Db)
+    a.set_option("i8_variant", 3)
+    Do, Io = oracle.knn(X, Q[:24], 10, "l2")
+    np.testing.assert_array_equal(Ib[:24], Io)
+    np.testing.assert_array_equal(Db[:24], Do)
+    for nq in (1, 64, 65, 128, 129, 256, 257, 777):       # 1 / 2 / 4 waves per workgroup, then the batch shape with padding waves
+        for ring, nt in ((0, 0), (2, 1), (8, 0), (4, 1)):
+            a.set_option("i8_ring", ring)
+            a.set_option("i8_nt", nt)
+            Da, Ia = a.search(Q[:nq], 10)
+            assert a.stats()["scan_dtype"] == 1
+            np.testing.assert_array_equal(Ia, Ib[:nq])
+            np.testing.assert_array_equal(Da, Db[:nq])
+    a.close()
+    b.close()
 
 
 def test_int8_copy_only_for_byte_valued_corpora(vdb):

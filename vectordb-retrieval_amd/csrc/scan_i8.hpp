@@ -25,7 +25,7 @@ typedef int int16v __attribute__((ext_vector_type(16)));
 //  int8-only build, where X is the block's base minus the rows in front of it: only rows of the block are touched)
 __global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
                                                               int ks32, int64_t ntiles, int cx,
-                                                              int4v *__restrict__ panels, int64_t tile0 = 0) {
+                                                              int4v *__restrict__ panels, int64_t tile0 = 0, int x16 = 0) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
@@ -34,12 +34,20 @@ __global__ __launch_bounds__(256) void build_panels_i8_kernel(const float *__res
     if (tile >= ntiles) return;
     tile += tile0;
     gid += tile0 * ks32 * 64;
-    const int rho = lane & 31, kh = lane >> 5;
-    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
     const int64_t span = tile / kTilesPerSpan;
     const int t = (int)(tile - span * kTilesPerSpan);
-    const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
-    const int d0 = ks * 32 + kh * 16;
+    int64_t row;
+    int d0;
+    if (x16) {       // layout "x16" (scan_i8x16.hpp): piece v = 2 ks2 + rb, lane = (MFMA row m of block rb, 16-dim quarter of the k-step)
+        const int m = lane & 15;
+        row = span * kSpanRows + (m >> 2) * 128 + t * 8 + (ks & 1) * 4 + (m & 3);
+        d0 = (ks >> 1) * 64 + (lane >> 4) * 16;
+    } else {
+        const int rho = lane & 31, kh = lane >> 5;
+        const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+        row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+        d0 = ks * 32 + kh * 16;
+    }
     int4v out;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -90,16 +98,22 @@ __global__ __launch_bounds__(256) void build_bias_i8_kernel(const float *__restr
 // value cq - q.  One thread per (qtile32, ks, lane).
 __device__ __forceinline__ void build_qpanels_i8_body(int64_t gid, const float *__restrict__ Q, int64_t nq, int D, int ks32,
                                                       int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
-                                                      int4v *__restrict__ qpanels) {
+                                                      int4v *__restrict__ qpanels, int x16 = 0) {
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
-    const int ks = (int)(tk % ks32);
-    const int64_t qt = tk / ks32;
     const int mode = info->i8_mode;
-    if (qt >= nqtiles || !mode) return;
+    if (tk >= nqtiles * ks32 || !mode) return;
     const int cq = (mode & 3) == 1 ? 127 : -1;
-    const int64_t q = qt * 32 + (lane & 31);
-    const int d0 = ks * 32 + (lane >> 5) * 16;
+    int64_t q;
+    int d0;
+    if (x16) {       // [q / 16][ks2][lane]: query column lane & 15, dims 64 ks2 + 16 (lane >> 4) .. +15 (same size as the 32-query form)
+        const int ks2n = ks32 / 2;
+        q = (tk / ks2n) * 16 + (lane & 15);
+        d0 = (int)(tk % ks2n) * 64 + (lane >> 4) * 16;
+    } else {
+        q = (tk / ks32) * 32 + (lane & 31);
+        d0 = (int)(tk % ks32) * 32 + (lane >> 5) * 16;
+    }
     int4v out;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -118,8 +132,8 @@ __device__ __forceinline__ void build_qpanels_i8_body(int64_t gid, const float *
 
 __global__ __launch_bounds__(256) void build_qpanels_i8_kernel(const float *__restrict__ Q, int64_t nq, int D, int ks32,
                                                                int64_t nqtiles, const QueryBatchInfo *__restrict__ info,
-                                                               int4v *__restrict__ qpanels) {
-    build_qpanels_i8_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, Q, nq, D, ks32, nqtiles, info, qpanels);
+                                                               int4v *__restrict__ qpanels, int x16 = 0) {
+    build_qpanels_i8_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, Q, nq, D, ks32, nqtiles, info, qpanels, x16);
 }
 
 // row-major int8 copy for the list refine (refine.hpp, RefineCommon.X8): rows[row][pitch] = x - cx, bytes beyond D hold
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void build_rows_i8_kernel(const float *__restr
 __global__ __launch_bounds__(256) void convert_slab_from_i8_kernel(const int4v *__restrict__ panels8, int ks32, int ksteps, int cx,
                                                                    int64_t tile0, int64_t ntiles, int64_t N, int D,
                                                                    const QueryBatchInfo *__restrict__ info,
-                                                                   half8 *__restrict__ out) {
+                                                                   half8 *__restrict__ out, int x16 = 0) {
     if (info->i8_mode) return;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
@@ -163,10 +177,17 @@ __global__ __launch_bounds__(256) void convert_slab_from_i8_kernel(const int4v *
     const int64_t span = tile / kTilesPerSpan;
     const int t = (int)(tile - span * kTilesPerSpan);
     const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
-    const int o = (ks & 1) * 16 + kh * 8;                       // dim offset inside the 32-dim int8 k-step
-    const int4v src = panels8[((size_t)tile * ks32 + (ks >> 1)) * 64 + rho + 32 * (o >> 4)];
-    const int w0 = src[(o & 15) >> 2], w1 = src[((o & 15) >> 2) + 1];
     const int d0 = ks * 16 + kh * 8;
+    int4v src;
+    if (x16) {       // layout "x16": row offset ro in the span -> (lane group, int8 tile, block, row of the quad); dims -> (k-step, quarter)
+        const int ro = h * kBinRows + t * 16 + r;
+        const int m = (ro >> 7) * 4 + (ro & 3), t8 = (ro & 127) >> 3, rb = (ro >> 2) & 1;
+        src = panels8[((size_t)(span * kTilesPerSpan + t8) * ks32 + (d0 >> 6) * 2 + rb) * 64 + ((d0 & 63) >> 4) * 16 + m];
+    } else {
+        const int o = (ks & 1) * 16 + kh * 8;                   // dim offset inside the 32-dim int8 k-step
+        src = panels8[((size_t)tile * ks32 + (ks >> 1)) * 64 + rho + 32 * (o >> 4)];
+    }
+    const int w0 = src[(d0 & 15) >> 2], w1 = src[((d0 & 15) >> 2) + 1];
     half8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -744,6 +765,7 @@ struct QueryPrepArgs {
     const QueryBatchInfo *info;
     half8 *qpanels;
     int4v *qpanels8;            // nullptr: no int8 scan offered
+    int x16;                    // the int8 B fragments in the 16-query form (scan_i8x16.hpp)
     signed char *qrows8;        // nullptr: no int8 refine rows
     EpsArgs eps;
     unsigned nA, nB, nC;        // region boundaries in workgroups
@@ -800,7 +822,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepArgs a) {
     if (b < a.nA)
         build_qpanels_body((int64_t)b * 256 + threadIdx.x, a.Q, a.nq, a.D, a.D4, a.ksteps, a.nqtiles, a.info, a.qpanels);
     else if (b < a.nB)
-        build_qpanels_i8_body((int64_t)(b - a.nA) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.ks32, a.nqtiles, a.info, a.qpanels8);
+        build_qpanels_i8_body((int64_t)(b - a.nA) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.ks32, a.nqtiles, a.info, a.qpanels8, a.x16);
     else if (b < a.nC)
         qrows_i8_body((int64_t)(b - a.nB) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.pitch8, a.info, a.qrows8);
     else
