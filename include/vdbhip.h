@@ -80,7 +80,9 @@ typedef struct vdb_stats_s {
     int64_t upload_blocks;     /* row blocks the last vdb_add / vdb_ivf_add streamed through the pinned staging buffers */
     int64_t graph_replays;     /* searches served by launching the captured hipGraph (option "graph") since the handle was made */
     int32_t ndevices;          /* shards of the handle: 1, or the ndev of vdb_create_multi (sums / maxima over the shards above) */
-    int32_t reserved0;
+    int32_t scan_shape;        /* rows of the MFMA tile the flat scan copies (D <= 128) are laid out for: 16 = layout "x16"
+                                  (v_mfma_*_16x16x32_f16 / 16x16x64_i8, the default above 15 360 rows), 32 = 32x32x16 / 32x32x32
+                                  (option "flat_shape" = 32, small corpora, quads); 0 = no such copy (D > 128, empty index) */
     int64_t bytes_workspace;   /* the part of bytes_resident that is per-search workspace (bin arrays, work lists, staging) */
     float last_prep_ms;        /* timing on: mean time from the start of the device pipeline to the start of the dominant kernel
                                   (query statistics / operands; IVF: + coarse search, plan) ... */
@@ -245,6 +247,10 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *     "i8_variant"      0..7: tile / stage / wave shapes of the flat int8 scan (6 / 7: variant 3 with a pacing barrier
  *                       per 1 / 2 tiles)
  *     "i8_group"        8 (default) | 4 rows per select group of the flat int8 scan
+ *     "flat_shape"      (before vdb_add; alias "i8_shape") MFMA shape of the flat scans for D <= 128 and the layout of their scan
+ *                       copies: 0 auto (16) | 16 | 32.  16 = v_mfma_f32_16x16x32_f16 / v_mfma_i32_16x16x64_i8 on layout "x16"
+ *                       (octs only; +17 - 19 % on the scans); 32 = the 32x32 kernels (also taken when an option asks for quads
+ *                       -- "f16_group" / "i8_group" = 4 -- or for an A/B schedule of "scan_variant")
  *     "f16_group"       8 (default) | 4 rows per select group of the fp16 flat scan (D <= 128)
  *     "i8_ring"         0 auto (4) | 2 | 4 | 8 LDS staging stages of the serving-shaped and IVF int8 scans
  *     "i8_nt"           0 (default) / 2: the serving-shaped int8 scan stages its panels with non-temporal loads | 1 off

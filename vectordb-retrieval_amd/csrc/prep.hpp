@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void corpus_stats_kernel(const float *__restri
 // one thread per (tile, kstep, lane): converts 8 consecutive dims of one corpus row.
 __global__ __launch_bounds__(256) void build_panels_kernel(const float *__restrict__ X, int64_t N, int D, int D4,
                                                            int ksteps, int64_t ntiles, float sx,
-                                                           half8 *__restrict__ panels, IndexStats *st) {
+                                                           half8 *__restrict__ panels, IndexStats *st, int x16 = 0) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
@@ -73,12 +73,20 @@ __global__ __launch_bounds__(256) void build_panels_kernel(const float *__restri
     const int64_t tile = tk / ksteps;
     int inexact = 0;
     if (tile < ntiles) {
-        const int rho = lane & 31, kh = lane >> 5;
-        const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
         const int64_t span = tile / kTilesPerSpan;
         const int t = (int)(tile - span * kTilesPerSpan);
-        const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
-        const int d0 = ks * 16 + kh * 8;
+        int64_t row;
+        int d0;
+        if (x16) {     // layout "x16" (scan_x16.hpp): piece v = 2 ks2 + rb, lane = (MFMA row m of block rb, 8-dim quarter of the 32-dim k-step)
+            const int m = lane & 15;
+            row = span * kSpanRows + (m >> 2) * 128 + t * 8 + (ks & 1) * 4 + (m & 3);
+            d0 = (ks >> 1) * 32 + (lane >> 4) * 8;
+        } else {
+            const int rho = lane & 31, kh = lane >> 5;
+            const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+            row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+            d0 = ks * 16 + kh * 8;
+        }
         half8 out;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -296,15 +304,21 @@ __global__ __launch_bounds__(256) void query_stats_kernel(const float *__restric
 __device__ __forceinline__ void build_qpanels_body(int64_t gid, const float *__restrict__ Q, int64_t nq, int D, int D4,
                                                    int ksteps, int64_t nqtiles,
                                                    const QueryBatchInfo *__restrict__ info,
-                                                   half8 *__restrict__ qpanels) {
+                                                   half8 *__restrict__ qpanels, int x16 = 0) {
     const int lane = (int)(gid & 63);
     const int64_t tk = gid >> 6;
-    const int ks = (int)(tk % ksteps);
-    const int64_t qt = tk / ksteps;
-    if (qt >= nqtiles || info->i8_mode) return;
+    if (tk >= nqtiles * ksteps || info->i8_mode) return;
     const float bs = info->bscale;
-    const int64_t q = qt * 32 + (lane & 31);
-    const int d0 = ks * 16 + (lane >> 5) * 8;
+    int64_t q;
+    int d0;
+    if (x16) {     // [q / 16][ks2][lane]: query column lane & 15, dims 32 ks2 + 8 (lane >> 4) .. +7 (same size as the 32-query form)
+        const int ks2n = ksteps / 2;
+        q = (tk / ks2n) * 16 + (lane & 15);
+        d0 = (int)(tk % ks2n) * 32 + (lane >> 4) * 8;
+    } else {
+        q = (tk / ksteps) * 32 + (lane & 31);
+        d0 = (int)(tk % ksteps) * 16 + (lane >> 5) * 8;
+    }
     half8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void build_rows_i8_kernel(const float *__restr
 }
 
 // ---- int8-only indexes (option "int8_only"): the fp16 scan copy of a slab of tiles, converted from the int8 panels per search ---
+// (x16 = 1: both copies in layout "x16".)
 // fp16 piece (tile, 16-dim k-step ks, lane = (row rho, k half kh)) = dims [16 ks + 8 kh, +8) of MFMA row rho = 8 consecutive bytes
 // of the int8 piece (tile, ks / 2, lane' = rho + 32 * ((ks & 1) * 16 + 8 kh >= 16)) -- values byte + cx, exact in fp16.  Rows past N and
 // dims past D hold A = 0 in the int8 panels (x = cx there), so those positions must come out as 0: `N`, `D` are re-checked here.
@@ -172,18 +173,21 @@ __global__ __launch_bounds__(256) void convert_slab_from_i8_kernel(const int4v *
     const int64_t tl = tk / ksteps;
     if (tl >= ntiles) return;
     const int64_t tile = tile0 + tl;
-    const int rho = lane & 31, kh = lane >> 5;
-    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
     const int64_t span = tile / kTilesPerSpan;
     const int t = (int)(tile - span * kTilesPerSpan);
-    const int64_t row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
-    const int d0 = ks * 16 + kh * 8;
+    int64_t row;
+    int d0;
     int4v src;
-    if (x16) {       // layout "x16": row offset ro in the span -> (lane group, int8 tile, block, row of the quad); dims -> (k-step, quarter)
-        const int ro = h * kBinRows + t * 16 + r;
-        const int m = (ro >> 7) * 4 + (ro & 3), t8 = (ro & 127) >> 3, rb = (ro >> 2) & 1;
-        src = panels8[((size_t)(span * kTilesPerSpan + t8) * ks32 + (d0 >> 6) * 2 + rb) * 64 + ((d0 & 63) >> 4) * 16 + m];
+    if (x16) {       // both copies in layout "x16": fp16 piece v = 2 ks2 + rb of the tile <- the int8 piece of the same block rb that holds its 8 dims
+        const int m = lane & 15, rb = ks & 1;
+        row = span * kSpanRows + (m >> 2) * 128 + t * 8 + rb * 4 + (m & 3);
+        d0 = (ks >> 1) * 32 + (lane >> 4) * 8;
+        src = panels8[((size_t)tile * ks32 + (d0 >> 6) * 2 + rb) * 64 + ((d0 & 63) >> 4) * 16 + m];
     } else {
+        const int rho = lane & 31, kh = lane >> 5;
+        const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+        row = span * kSpanRows + (int64_t)h * kBinRows + t * 16 + r;
+        d0 = ks * 16 + kh * 8;
         const int o = (ks & 1) * 16 + kh * 8;                   // dim offset inside the 32-dim int8 k-step
         src = panels8[((size_t)tile * ks32 + (ks >> 1)) * 64 + rho + 32 * (o >> 4)];
     }
@@ -765,7 +769,7 @@ struct QueryPrepArgs {
     const QueryBatchInfo *info;
     half8 *qpanels;
     int4v *qpanels8;            // nullptr: no int8 scan offered
-    int x16;                    // the int8 B fragments in the 16-query form (scan_i8x16.hpp)
+    int x16;                    // B fragments (fp16 and int8) in the 16-query form of layout "x16" (scan_x16.hpp, scan_i8x16.hpp)
     signed char *qrows8;        // nullptr: no int8 refine rows
     EpsArgs eps;
     unsigned nA, nB, nC;        // region boundaries in workgroups
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepArgs a) {
         a.eps.info = &s_info;
     }
     if (b < a.nA)
-        build_qpanels_body((int64_t)b * 256 + threadIdx.x, a.Q, a.nq, a.D, a.D4, a.ksteps, a.nqtiles, a.info, a.qpanels);
+        build_qpanels_body((int64_t)b * 256 + threadIdx.x, a.Q, a.nq, a.D, a.D4, a.ksteps, a.nqtiles, a.info, a.qpanels, a.x16);
     else if (b < a.nB)
         build_qpanels_i8_body((int64_t)(b - a.nA) * 256 + threadIdx.x, a.Q, a.nq, a.D, a.ks32, a.nqtiles, a.info, a.qpanels8, a.x16);
     else if (b < a.nC)

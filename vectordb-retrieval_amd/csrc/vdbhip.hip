@@ -20,6 +20,7 @@
 #include "scan16.hpp"
 #include "scan_i8.hpp"
 #include "scan_i8x16.hpp"
+#include "scan_x16.hpp"
 #include "ivf.hpp"
 #include "ivf_mfma.hpp"
 #include "ivf_kloop.hpp"
@@ -194,8 +195,10 @@ struct vdb_index_s {
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
-    int i8_shape_opt = 0;                    // option "i8_shape" (before vdb_add): MFMA shape of the flat int8 scan, 0 auto (16) | 16 | 32
-    bool i8_x16 = false;                     // the flat int8 panels are in layout "x16" (scan_i8x16.hpp: 16x16x64 MFMA, octs only)
+    int flat_shape_opt = 0;                  // option "flat_shape" (alias "i8_shape"; before vdb_add): MFMA shape of the flat scans for D <= 128,
+                                             // 0 auto (16) | 16 | 32
+    bool x16 = false;                        // the flat scan copies (fp16 and int8, D <= 128) are in layout "x16": 16x16x32 f16 / 16x16x64 i8 MFMA,
+                                             // octs only (scan_x16.hpp, scan_i8x16.hpp); corpora the dense small-corpus path serves keep 32-row tiles
     int f16_group = 8;                       // ... and of the fp16 flat scan (option "f16_group": 4 or 8)
     // option "int8_only" (takes effect at the next add; flat index, D <= 128, > 32768 rows, byte-valued corpus): only the int8
     // copies are kept -- rows8 + panels8 + their biases, 0.55x the float32 corpus instead of 3x.  Integer query batches run as on
@@ -467,6 +470,13 @@ void build_rows_i8(vdb_index_s *h, hipStream_t st) {
 
 void graph_reset(vdb_index_s *h);
 
+// layout "x16" for the scan copies of a D <= 128 flat index, unless an option asks for what only the 32-row kernels have
+// (quads as the candidate group, the A/B schedules and ablations behind scan_variant, panel_layout 1)
+bool x16_wanted(const vdb_index_s *h) {
+    return h->ksteps <= kMaxKSteps && h->flat_shape_opt != 32 && h->layout_override != 1 && h->f16_group == 8 && h->i8_group == 8 &&
+           h->scan_variant == 0;
+}
+
 // everything derived from the h->N rows in h->x32: statistics, scan copies, biases
 void build_derived(vdb_index_s *h, hipStream_t st) {
     const int D = h->dim, D4 = h->D4;
@@ -480,6 +490,7 @@ void build_derived(vdb_index_s *h, hipStream_t st) {
                                             (h->layout_override == 2 && n > kDenseMaxRows));
     const int64_t span_rows = h->tile16 ? kSpanRows16 : kSpanRows;
     h->Npad = (n + span_rows - 1) / span_rows * span_rows;
+    h->x16 = x16_wanted(h) && !h->tile16 && h->Npad > kDenseMaxRows;
     h->scan_ok = false;
     if (n == 0) {
         h->built = true;
@@ -497,7 +508,7 @@ void build_derived(vdb_index_s *h, hipStream_t st) {
         if (h->tile16)    // (streamed: the pass only takes the fp16-exactness flag)
             build_panels16_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, ksl, ntiles, h->sx, h->panels_streamed ? nullptr : h->panels.as<half8>(), h->stats.as<IndexStats>());
         else
-            build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>());
+            build_panels_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->x32.as<float>(), n, D, D4, h->ksteps, ntiles, h->sx, h->panels.as<half8>(), h->stats.as<IndexStats>(), h->x16 ? 1 : 0);
         VDB_HIP(hipGetLastError());
         h->bias.reserve((size_t)h->Npad * sizeof(float));
         build_bias_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(h->xnorm2.as<float>(), n, h->Npad, h->metric, h->bias.as<float>());
@@ -510,11 +521,10 @@ void build_derived(vdb_index_s *h, hipStream_t st) {
         h->i8_ok = h->i8_ok && !h->tile16;
         if (h->i8_ok) {
             h->i8_ks = D <= 64 ? 2 : 4;
-            h->i8_x16 = h->i8_shape_opt != 32 && h->i8_group == 8;
             h->panels8.reserve((size_t)ntiles * h->i8_ks * 64 * sizeof(int4v));
             const int64_t t8 = ntiles * h->i8_ks * 64;
             build_panels_i8_kernel<<<dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st>>>(
-                h->x32.as<float>(), n, D, D4, h->i8_ks, ntiles, h->i8_cx, h->panels8.as<int4v>(), 0, h->i8_x16 ? 1 : 0);
+                h->x32.as<float>(), n, D, D4, h->i8_ks, ntiles, h->i8_cx, h->panels8.as<int4v>(), 0, h->x16 ? 1 : 0);
             h->bias8.reserve((size_t)2 * h->Npad * sizeof(int32_t));
             h->rowstat8.reserve((size_t)n * 2 * sizeof(int));
             build_bias_i8_kernel<<<dim3((unsigned)((h->Npad + 255) / 256)), dim3(256), 0, st>>>(
@@ -554,6 +564,7 @@ bool build_int8_only(vdb_index_s *h, const float *x, bool on_device, int64_t n, 
     for (auto b : gone) b->release();
     h->Npad = (n + kSpanRows - 1) / kSpanRows * kSpanRows;
     h->i8_ks = D <= 64 ? 2 : 4;
+    h->x16 = x16_wanted(h);                 // (more than 32 768 rows: never the dense path's)
     h->rows8_pitch = h->i8_ks * 32;
     const int64_t ntiles = h->Npad / kTileRows;
     h->rows8.reserve_exact((size_t)n * h->rows8_pitch);
@@ -604,7 +615,7 @@ bool build_int8_only(vdb_index_s *h, const float *x, bool on_device, int64_t n, 
             const int64_t row_end = last ? h->Npad : r1;
             const int64_t t0 = r0 / kTileRows, nt = (row_end - r0) / kTileRows;
             build_panels_i8_kernel<<<dim3((unsigned)((nt * h->i8_ks * 64 + 255) / 256)), dim3(256), 0, st>>>(
-                fake, r1, D, D4, h->i8_ks, nt, cx, h->panels8.as<int4v>(), t0, h->i8_x16 ? 1 : 0);
+                fake, r1, D, D4, h->i8_ks, nt, cx, h->panels8.as<int4v>(), t0, h->x16 ? 1 : 0);
             build_bias_i8_kernel<<<dim3((unsigned)((row_end - r0 + 255) / 256)), dim3(256), 0, st>>>(
                 fake, r1, h->Npad, D, D4, h->metric, h->bias8.as<int32_t>(), h->rowstat8.as<int>(), r0, row_end);
             VDB_HIP(hipGetLastError());
@@ -1080,6 +1091,7 @@ int vdb_stats(vdb_handle hh, vdb_stats_t *out) {
         set_device(h->device);
         vdb_stats_t s = h->last;
         s.ndevices = 1;
+        s.scan_shape = (!h->scan_ok || h->ksteps > kMaxKSteps || h->N == 0) ? 0 : h->x16 ? 16 : h->tile16 ? 16 : 32;
         s.ntotal = h->N;
         s.dim = h->dim;
         s.metric = h->metric;
@@ -1244,9 +1256,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "i8_group") {          // rows per select group of the int8 scan: 8 (octs, default) or 4 (quads)
             if (value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "i8_group must be 4 or 8");
             h->i8_group = (int)value;
-        } else if (k == "i8_shape") {          // MFMA shape of the flat int8 scan (layout of the int8 panels: set before vdb_add)
-            if (value != 0 && value != 16 && value != 32) throw Error(VDB_ERR_INVALID, "i8_shape must be 0 (auto), 16 or 32");
-            h->i8_shape_opt = (int)value;
+        } else if (k == "flat_shape" || k == "i8_shape") {   // MFMA shape of the flat scans, D <= 128 (layout of the scan copies: set before vdb_add)
+            if (value != 0 && value != 16 && value != 32) throw Error(VDB_ERR_INVALID, "flat_shape must be 0 (auto), 16 or 32");
+            h->flat_shape_opt = (int)value;
         } else if (k == "int8_only") {
             if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "int8_only must be 0 or 1");
             h->int8_only_opt = (int)value;

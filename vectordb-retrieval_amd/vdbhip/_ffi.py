@@ -33,7 +33,7 @@ class Stats(Structure):
         ("scan_dtype", c_int32), ("has_i8_copy", c_int32), ("last_rows_scanned", c_int64),
         ("upload_blocks", c_int64),
         ("graph_replays", c_int64),
-        ("ndevices", c_int32), ("reserved0", c_int32), ("bytes_workspace", c_int64), ("last_prep_ms", c_float), ("last_tail_ms", c_float),
+        ("ndevices", c_int32), ("scan_shape", c_int32), ("bytes_workspace", c_int64), ("last_prep_ms", c_float), ("last_tail_ms", c_float),
     ]
 
     def as_dict(self):
