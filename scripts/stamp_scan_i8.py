@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic build of the int8 flat scan (i8_variant + 16, ablations library): where the cycles of scan_i8_kernel<4,8,4>
-go.  Per wave the kernel sums shader cycles (s_memtime) over the phases of every stage -- head (next stage's LDS-DMA issue
+"""Diagnostic build of the int8 flat scan (i8_variant + 16, ablations library): where the cycles of scan_i8x16_kernel<2,8,8>
+(default) or, with argument 32, of scan_i8_kernel<4,8,4> (option flat_shape = 32) go.  Per wave the kernel sums shader cycles (s_memtime) over the phases of every stage -- head (next stage's LDS-DMA issue
 + first fragment reads), MFMA phases (until the matrix pipe has delivered), select phases (+ the next tile's fragment
 reads), tail (bin flush + bias store), barrier wait -- and reads s_memrealtime over the same span: the in-kernel clock is
 cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  Results stay exact; the stamped kernel is slower
@@ -14,11 +14,14 @@ import numpy as np, torch, vdbhip
 from vdbhip import _ffi
 from bench import make_data
 X, Q, k, metric = make_data("sift1m", 0)
-idx = vdbhip.FlatIndex(X.shape[1], metric, 0); idx.add(X)
+shape = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+idx = vdbhip.FlatIndex(X.shape[1], metric, 0); idx.set_option("flat_shape", shape); idx.add(X)
 D0, I0 = idx.search(Q, k)
-for variant, name in ((16 + 3, "scan_i8_kernel<4,8,4> (1024-query tiles, 8-tile stages)"),
-                      (16 + 6, "scan_i8_kernel<4,8,4> + a pacing s_barrier per tile (i8_variant 6)"),
-                      (16 + 1, "scan_i8_kernel<4,8,2> (512-query tiles)")):
+assert idx.stats()["scan_shape"] == shape
+for variant, name in (((16 + 3, "scan_i8x16_kernel<2,8,8> (16x16x64 MFMA, 1024-query tiles, 8-tile stages)"),) if shape == 16 else
+                      ((16 + 3, "scan_i8_kernel<4,8,4> (1024-query tiles, 8-tile stages)"),
+                       (16 + 6, "scan_i8_kernel<4,8,4> + a pacing s_barrier per tile (i8_variant 6)"),
+                       (16 + 1, "scan_i8_kernel<4,8,2> (512-query tiles)"))):
     idx.set_option("i8_variant", variant)
     for _ in range(25):        # (the clock settles under back-to-back launches)
         D, I = idx.search(Q, k)

@@ -7,14 +7,14 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
-WANT = {  # pass group -> (json key, substrings the kernel name must contain)
-    "sift1m": ("sift1m_i8", ("scan_i8_kernel", "false")),
+WANT = {  # pass group -> (json key, substrings the kernel name must contain; "a|b" = either)
+    "sift1m": ("sift1m_i8", ("scan_i8x16_kernel|scan_i8_kernel",)),
     "ivf8": ("ivf1024_nprobe8", ("scan_i8_kernel", "true")),
     "ivf128": ("ivf1024_nprobe128", ("scan_i8_kernel", "true")),
     "msmarco": ("msmarco_ivf_nprobe32", ("ivf_kloop_scan_kernel",)),
     "ivf32": ("ivf1024_nprobe32", ("scan_i8_kernel", "true")),
-    "gaussian": ("gaussian1m", ("scan_kernel<8",)),
-    "glove": ("glove1.2m", ("scan_kernel<4",)),
+    "gaussian": ("gaussian1m", ("scan_x16_kernel<4|scan_kernel<8",)),
+    "glove": ("glove1.2m", ("scan_x16_kernel<2|scan_kernel<4",)),
     "marco": ("marco12.5m", ("scan16_kloop_kernel",)),
 }
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r03"
@@ -30,7 +30,7 @@ table = json.load(open(out)) if os.path.exists(out) else {}
 for group, (key, must) in WANT.items():
     best = None
     for kernel, cs in vals.get(group, {}).items():
-        if not all(m in kernel for m in must) or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+        if not all(any(alt in kernel for alt in m.split("|")) for m in must) or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
             continue
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
@@ -41,7 +41,7 @@ for group, (key, must) in WANT.items():
         continue
     kernel, fetch, write, launches = best
     keep = {k: v for k, v in table.get(key, {}).items() if k == "algorithmic_bytes_per_launch"}
-    table[key] = {"kernel": kernel.replace("void vdb::", "").replace("(vdb::ScanI8Args)", "").replace(" ", ""),
+    table[key] = {"kernel": kernel.replace("void vdb::", "").replace("(vdb::ScanI8Args)", "").replace("(vdb::ScanArgs)", "").replace(" ", ""),
                   "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
                   "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "launches_averaged": launches, "correction": CORR,
                   "source": f"profiles/{TAG}_pmc_summary.txt (scripts/final_profiles_{TAG}.sh, separate --pmc passes '{group}_fetch' / '{group}_write')",
