@@ -23,7 +23,7 @@ pmc() {    # name, counters..., then -- bench args
   timeout -k 10 240 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $OUT/pmc_$name -o $name -- \
       python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/pmc_$name.log 2>&1 || echo "pmc pass $name failed"
 }
-PHASE=${1:-all}     # all | stats (bench line, kernel stats, breakdowns) | pmc | pmc1 | pmc2 (counter passes, stamps)
+PHASE=${1:-all}     # all | stats (bench line, kernel stats, breakdowns) | pmc | pmc1 | pmc2 (counter passes, stamps) | pmcx (the flat scans only)
 if [ "$PHASE" = "all" ] || [ "$PHASE" = "stats" ]; then
 python3 $R/__graft_entry__.py smoke > $OUT/smoke.txt 2>&1 || echo "smoke failed"
 echo "== bench (driver command)"; date
@@ -43,6 +43,22 @@ if true; then
   prof marco --workload marco12.5m --steps 5 --warmup 2
 fi
 fi   # stats phase
+if [ "$PHASE" = "pmcx" ]; then      # the three flat scans on layout "x16" (the IVF / K-loop kernels did not change)
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
+pmc sift1m_sq $SQ1 --
+pmc sift1m_fetch FETCH_SIZE --
+pmc sift1m_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --
+pmc sift1m_grbm GRBM_GUI_ACTIVE GRBM_COUNT --
+for w in gaussian1m glove1.2m; do
+  n=${w%%1*}
+  pmc ${n}_sq $SQ1 -- --workload $w
+  pmc ${n}_fetch FETCH_SIZE -- --workload $w
+  pmc ${n}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- --workload $w
+  pmc ${n}_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- --workload $w
+done
+cd $R
+exit 0
+fi
 if [ "$PHASE" != "stats" ]; then
 echo "== PMC passes"; date
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"

@@ -40,6 +40,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
     constexpr int TPS = kTilesPerSpan;                    // 16 tiles of 32 rows
     constexpr int SPS = TPS / ST;
     constexpr int HC = CB / 2;                            // column blocks whose bins a lane stores
+    // tiles of a stage unrolled together: the serving shapes (one wave per SIMD, nothing to overlap with but the wave's own next
+    // tile); the batch shape keeps the tile loop rolled (as scan_i8_kernel)
+    constexpr int UNR = (ST * CB <= 16) ? ST : 1;
     static_assert(TPS % ST == 0 && ST >= 2 && CB % 2 == 0 && NWAVES <= 8, "bad geometry");
     static_assert(RING >= 2 && RING <= 8 && (RING == 2 || ST % 2 == 0), "bad ring");
     constexpr bool kDeep = RING > 2;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
             const int ts0 = (st % SPS) * ST;
             read_phase(A, B4);
             tick(c_head);
-#pragma unroll 1
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase();
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
             const int4v *B4 = reinterpret_cast<const int4v *>(lds_b(buf)) + g * 2;
             const int ts0 = (st % SPS) * ST;
             tick(c_head);
-#pragma unroll 1
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase(A + t * NV * 64, B4 + t * 8);
