@@ -16,7 +16,7 @@
 //   * panels8[tile][v = 2 ks2 + rb][lane][16 x int8]: lane holds MFMA row (lane & 15), dims 64 ks2 + 16 (lane >> 4) .. +15
 //     (same bytes per tile as the 32-row layout: 2 or 4 KiB); qpanels8[q / 16][ks2][lane]: query column (lane & 15), same dims.
 //   * a bin is complete after 16 tiles: the two lane groups of a half exchange their minima (ds_swizzle, lane ^ 16), both
-//     merge, and each stores half of the wave's query columns -- ~40 vector operations per 16 tiles beside ~800 of select.
+//     merge, and each stores every other column block of the wave -- ~40 vector operations per 16 tiles beside ~800 of select.
 #pragma once
 #include "scan_i8.hpp"
 
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
     int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
     const int64_t out_pitch = a.Qpad;
-    const int64_t col0 = q0 + (odd ? HC * 16 : 0) + (lane & 15);      // first of the HC query columns this lane stores
+    // the two lane groups of a span half share the stores of its bins: the even group takes column blocks 0, 2, 4, .., the odd one
+    // 1, 3, 5, ..: one store instruction then writes 32 consecutive queries = a whole 128-byte line per bin
+    const int64_t col0 = q0 + (odd ? 16 : 0) + (lane & 15);
     const int32_t *bias = a.bias8 + ((mode & 3) == 1 ? 0 : a.Npad);
 
     int4v bq[CB][KS2];
@@ -148,15 +150,15 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
         const size_t o = (size_t)(span * 2 + h) * out_pitch + col0;
 #pragma unroll
         for (int j = 0; j < HC; ++j) {
-            const int p1 = swap16(odd ? m1[j] : m1[j + HC]), p2 = swap16(odd ? m2[j] : m2[j + HC]);
-            const int a1 = odd ? m1[j + HC] : m1[j], a2 = odd ? m2[j + HC] : m2[j];
+            const int p1 = swap16(odd ? m1[2 * j] : m1[2 * j + 1]), p2 = swap16(odd ? m2[2 * j] : m2[2 * j + 1]);
+            const int a1 = odd ? m1[2 * j + 1] : m1[2 * j], a2 = odd ? m2[2 * j + 1] : m2[2 * j];
             const int b1 = imin(a1, p1), b2 = imin(imax(a1, p1), imin(a2, p2));
 #ifdef VDB_ABLATIONS
             if (!a.abl_no_bins)
 #endif
             {
-                __builtin_nontemporal_store(__int_as_float(b1), a.bin_m1 + o + j * 16);
-                __builtin_nontemporal_store(__int_as_float(b2), a.bin_m2 + o + j * 16);
+                __builtin_nontemporal_store(__int_as_float(b1), a.bin_m1 + o + j * 32);
+                __builtin_nontemporal_store(__int_as_float(b2), a.bin_m2 + o + j * 32);
             }
             M2[j] = imin(imed3(M1[j], M2[j], b1), b2);
             if (b1 < M1[j]) Ms[j] = (int)span;
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
     const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + col0;
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
-        a.sb_m1[so + j * 16] = __int_as_float(M1[j]);
-        a.sb_m2[so + j * 16] = __int_as_float(M2[j]);
-        a.sb_span[so + j * 16] = Ms[j];
+        a.sb_m1[so + j * 32] = __int_as_float(M1[j]);
+        a.sb_m2[so + j * 32] = __int_as_float(M2[j]);
+        a.sb_span[so + j * 32] = Ms[j];
     }
 }
 

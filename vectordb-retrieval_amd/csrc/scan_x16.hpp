@@ -50,7 +50,9 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
     const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
     int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
-    const int64_t col0 = q0 + ((kMerge && odd) ? NS * 16 : 0) + (lane & 15);     // first of the NS query columns this lane stores
+    // merged bins: the even lane group of a half stores column blocks 0, 2, the odd one 1, 3 (whole 128-byte lines per store)
+    const int64_t col0 = q0 + ((kMerge && odd) ? 16 : 0) + (lane & 15);
+    constexpr int CS = kMerge ? 32 : 16;                   // query columns between the blocks a lane stores
     const float cs = a.info->cs;
 
     half8 bq[CB][KS2];
@@ -113,12 +115,12 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
             const size_t o = (size_t)(span * 2 + h) * a.Qpad + col0;
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const float p1 = __int_as_float(swap16(__float_as_int(odd ? m1[j] : m1[j + NS])));
-                const float p2 = __int_as_float(swap16(__float_as_int(odd ? m2[j] : m2[j + NS])));
-                const float a1 = odd ? m1[j + NS] : m1[j], a2 = odd ? m2[j + NS] : m2[j];
+                const float p1 = __int_as_float(swap16(__float_as_int(odd ? m1[2 * j] : m1[2 * j + 1])));
+                const float p2 = __int_as_float(swap16(__float_as_int(odd ? m2[2 * j] : m2[2 * j + 1])));
+                const float a1 = odd ? m1[2 * j + 1] : m1[2 * j], a2 = odd ? m2[2 * j + 1] : m2[2 * j];
                 const float b1 = __builtin_fminf(a1, p1), b2 = __builtin_fminf(__builtin_fmaxf(a1, p1), __builtin_fminf(a2, p2));
-                __builtin_nontemporal_store(b1, a.bin_m1 + o + j * 16);
-                __builtin_nontemporal_store(b2, a.bin_m2 + o + j * 16);
+                __builtin_nontemporal_store(b1, a.bin_m1 + o + j * CS);
+                __builtin_nontemporal_store(b2, a.bin_m2 + o + j * CS);
                 M2[j] = __builtin_fminf(__builtin_amdgcn_fmed3f(M1[j], M2[j], b1), b2);
                 if (b1 < M1[j]) Ms[j] = (int)span;
                 M1[j] = __builtin_fminf(M1[j], b1);
@@ -274,9 +276,9 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
         const size_t so = (size_t)(chunk * 2 + h) * a.Qpad + col0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            a.sb_m1[so + j * 16] = M1[j];
-            a.sb_m2[so + j * 16] = M2[j];
-            a.sb_span[so + j * 16] = Ms[j];
+            a.sb_m1[so + j * CS] = M1[j];
+            a.sb_m2[so + j * CS] = M2[j];
+            a.sb_span[so + j * CS] = Ms[j];
         }
     }
 }
