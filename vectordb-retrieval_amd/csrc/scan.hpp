@@ -51,6 +51,7 @@ struct ScanArgs {
     int part_spans;              // items mode: spans per row part (blockIdx.y = part of the list this workgroup scans; 0 = whole list)
     const int32_t *slot_query;   // [slots] query + 1 of every slot (0 = padding)
     const _Float16 *qrows;       // [nq][16*KSTEPS] scaled fp16 query rows (B fragments are gathered from them)
+    int prio;                    // x16 kernels (option "scan_prio", tuning): 1 = the late half of a workgroup issues at priority 1, 2 = the early half
     unsigned long long *dbg;     // ABL == 4 (diagnostic build): per-wave cycle sums {head, mfma, select, barrier, total, late}
 };
 

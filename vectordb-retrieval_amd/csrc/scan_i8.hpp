@@ -228,6 +228,7 @@ struct ScanI8Args {
     const int32_t *item_list, *item_slot0, *item_bin0, *n_items, *list_pspan0, *slot_query;
     const signed char *qrows;    // [nq][32*KS] int8 query rows cq - q (B fragments are gathered from them)
     int part_spans;              // items mode: spans per row part (blockIdx.y), 0 = whole list (see ScanArgs)
+    int prio;                    // x16 kernel (option "scan_prio", tuning): 1 = the late half issues at priority 1, 2 = the early half
     int abl_no_bins;             // -DVDB_ABLATIONS builds only (timing, WRONG results): skip the level-1 bin stores
     unsigned long long *dbg;     // DBG builds (-DVDB_ABLATIONS): per wave {head, mfma, select, tail, barrier, total} shader
                                  // cycles, the s_memrealtime ticks of the same span, (stages << 1) | late

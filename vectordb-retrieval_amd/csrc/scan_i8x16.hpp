@@ -237,6 +237,8 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
     do {                                                                                                          \
         if (DBG) { _Pragma("unroll") for (int cb__ = 0; cb__ < CB; ++cb__) wait_for_mfma4(acc[0][cb__], acc[1][cb__]); } \
     } while (0)
+    if (a.prio == 1 && late) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2 && !late) __builtin_amdgcn_s_setprio(1);
     if (DBG) {
         t_first = t_last = stamp();
         r_first = realtime_ticks();

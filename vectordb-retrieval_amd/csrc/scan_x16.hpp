@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
     constexpr int BT = BR == 64 ? 8 : 16;                  // tiles per bin of a lane group
     constexpr bool kMerge = BR == 256;
     constexpr int NS = kMerge ? CB / 2 : CB;               // column blocks whose bins a lane stores
+    constexpr int UNR = ST <= 4 ? ST : 1;                  // tiles of a stage unrolled together (8-tile stages keep the loop rolled)
     static_assert(TPS % ST == 0 && ST >= 2 && BT % ST == 0 && (BR == 256 || BR == 128 || BR == 64), "bad geometry");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
@@ -198,6 +199,8 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
     do {                                                                                                              \
         if (DBG) { _Pragma("unroll") for (int cb__ = 0; cb__ < CB; ++cb__) asm volatile("s_nop 0" ::"v"(acc[0][cb__]), "v"(acc[1][cb__])); } \
     } while (0)
+    if (a.prio == 1 && late) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2 && !late) __builtin_amdgcn_s_setprio(1);
     if (DBG) t_start = stamp();
     if (!late) {
         for (int st = 0; st < nstages; ++st) {
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
             const int ts0 = (st % SPS) * ST;
             read_phase(A, B4);
             tick(c_head);
-#pragma unroll
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_phase();
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
             const float4v *B4 = reinterpret_cast<const float4v *>(lds_b(buf)) + g * 2;
             const int ts0 = (st % SPS) * ST;
             tick(c_head);
-#pragma unroll
+#pragma unroll UNR
             for (int t = 0; t < ST; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_phase(A + t * NV * 64, B4 + t * 8);

@@ -195,6 +195,8 @@ struct vdb_index_s {
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    int f16_stage_tiles = 0;                 // option "f16_stage_tiles" (tuning, x16 fp16 batch scan): tiles per LDS stage, 0 auto | 4 | 8
+    int scan_prio = 0;                       // option "scan_prio" (tuning, x16 kernels): issue priority of one half of the workgroup's waves
     int flat_shape_opt = 0;                  // option "flat_shape" (alias "i8_shape"; before vdb_add): MFMA shape of the flat scans for D <= 128,
                                              // 0 auto (16) | 16 | 32
     bool x16 = false;                        // the flat scan copies (fp16 and int8, D <= 128) are in layout "x16": 16x16x32 f16 / 16x16x64 i8 MFMA,
@@ -1287,6 +1289,12 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;
+        } else if (k == "f16_stage_tiles") {
+            if (value != 0 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "f16_stage_tiles must be 0, 4 or 8");
+            h->f16_stage_tiles = (int)value;
+        } else if (k == "scan_prio") {
+            if (value < 0 || value > 2) throw Error(VDB_ERR_INVALID, "scan_prio must be 0, 1 or 2");
+            h->scan_prio = (int)value;
         } else if (k == "scan_variant") {
 #ifdef VDB_ABLATIONS
             if (value < 0 || value >= kNumScanVariants) throw Error(VDB_ERR_INVALID, "scan_variant out of range");
