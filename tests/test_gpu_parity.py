@@ -573,6 +573,28 @@ def test_int8_x16_launch_shapes_equal_the_32x32x32_scan(vdb, oracle, n, d):
     b.close()
 
 
+def test_x16_tuning_options_do_not_change_results(vdb, oracle):
+    """`f16_stage_tiles` (4- / 8-tile LDS stages of the fp16 x16 scan) and `scan_prio` (issue priority of one half of a workgroup)."""
+    rng = np.random.default_rng(7)
+    for d in (64, 128):
+        X = rng.standard_normal((150_000, d)).astype(np.float32)
+        Q = rng.standard_normal((1100, d)).astype(np.float32)
+        idx = vdb.FlatIndex(d, "l2", 0)
+        idx.add(X)
+        D0, I0 = idx.search(Q, 10)
+        assert idx.stats()["scan_shape"] == 16 and idx.stats()["last_path_name"] == "mfma_scan"
+        Do, Io = oracle.knn(X, Q[:48], 10, "l2")
+        np.testing.assert_array_equal(I0[:48], Io)
+        np.testing.assert_array_equal(D0[:48], Do)
+        for opt, vals in (("f16_stage_tiles", (4, 8, 0)), ("scan_prio", (1, 2, 0))):
+            for v in vals:
+                idx.set_option(opt, v)
+                D, I = idx.search(Q, 10)
+                np.testing.assert_array_equal(I, I0)
+                np.testing.assert_array_equal(D, D0)
+        idx.close()
+
+
 def test_int8_copy_only_for_byte_valued_corpora(vdb):
     rng = np.random.default_rng(0)
     for X, want in ((rng.standard_normal((40000, 64)).astype(np.float32), 0),
