@@ -574,7 +574,8 @@ def test_int8_x16_launch_shapes_equal_the_32x32x32_scan(vdb, oracle, n, d):
 
 
 def test_x16_tuning_options_do_not_change_results(vdb, oracle):
-    """`f16_stage_tiles` (4- / 8-tile LDS stages of the fp16 x16 scan) and `scan_prio` (issue priority of one half of a workgroup)."""
+    """`f16_stage_tiles` (4- / 8-tile LDS stages of the fp16 x16 scan), `scan_prio` (issue priority of one half of a workgroup), and on
+    a byte-valued corpus `scan_pair` (both scans in one launch / two launches) for integer and non-integer batches of every launch shape."""
     rng = np.random.default_rng(7)
     for d in (64, 128):
         X = rng.standard_normal((150_000, d)).astype(np.float32)
@@ -586,12 +587,29 @@ def test_x16_tuning_options_do_not_change_results(vdb, oracle):
         Do, Io = oracle.knn(X, Q[:48], 10, "l2")
         np.testing.assert_array_equal(I0[:48], Io)
         np.testing.assert_array_equal(D0[:48], Do)
-        for opt, vals in (("f16_stage_tiles", (4, 8, 0)), ("scan_prio", (1, 2, 0))):
+        for opt, vals in (("f16_stage_tiles", (4, 8, 0)), ("scan_prio", (1, 2, 0)), ("scan_pair", (0, 1))):
             for v in vals:
                 idx.set_option(opt, v)
                 D, I = idx.search(Q, 10)
                 np.testing.assert_array_equal(I, I0)
                 np.testing.assert_array_equal(D, D0)
+        idx.close()
+    for d in (64, 128):
+        X, Q = _bytes_data(200_000, d, 1100, "u8", seed=d + 1)
+        idx = vdb.FlatIndex(d, "l2", 0)
+        idx.add(X)
+        for Qb, dtype in ((Q, 1), ((Q + 0.5).astype(np.float32), 0)):
+            for nq in (1, 100, 200, 1100):
+                idx.set_option("scan_pair", 1)
+                D1, I1 = idx.search(Qb[:nq], 10)
+                assert idx.stats()["scan_dtype"] == dtype
+                idx.set_option("scan_pair", 0)
+                D2, I2 = idx.search(Qb[:nq], 10)
+                np.testing.assert_array_equal(I1, I2)
+                np.testing.assert_array_equal(D1, D2)
+            Do, Io = oracle.knn(X, Qb[:40], 10, "l2")
+            np.testing.assert_array_equal(I1[:40], Io)
+            np.testing.assert_array_equal(D1[:40], Do)
         idx.close()
 
 

@@ -780,6 +780,8 @@ struct QueryPrepArgs {
     int fused_stats;
     FinalizeArgs fin;
     QueryBatchInfo *info_out;
+    unsigned *clear_small;      // fused_stats only: ws.small (kSmallBytes), cleared by workgroup 0 around the QueryBatchInfo at kInfoOffset
+                                // -- the kernels that count into it (select, refine) run behind this one
 };
 constexpr int64_t kFusedStatsMax = 4096;    // (measured on 1M x 128: 1 / 8 queries 74.8 -> 70.7 / 78.0 -> 75.0 us; at 64 queries = 8192 values the redundant pass costs what the dispatch saved)
 __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepArgs a) {
@@ -787,6 +789,9 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepArgs a) {
     __shared__ QueryBatchInfo s_info;
     __shared__ float s_max[4];
     __shared__ int s_flags[4];
+    if (a.clear_small && b == 0)
+        for (unsigned i = threadIdx.x; i < kSmallBytes / 4; i += 256)
+            if (i < kInfoOffset / 4 || i >= 16) a.clear_small[i] = 0u;          // (words [4, 16) = the QueryBatchInfo written below)
     if (a.fused_stats) {
         const int64_t total = a.nq * a.D;
         float amax = 0.f;

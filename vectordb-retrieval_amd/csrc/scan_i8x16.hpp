@@ -31,8 +31,13 @@ __device__ __forceinline__ int swap16(int v) { return __builtin_amdgcn_ds_swizzl
 // KS2: 64-dim k-steps (D padded to 64 or 128); ST: 32-row tiles per LDS stage; CB: 16-query column blocks per wave (8 -> 128
 // queries per wave, 4 -> 64); NWAVES, RING, AUX, DBG as scan_i8_kernel.  Octs only (QueryBatchInfo.i8_mode bit 2 is set by
 // the host for an index in this layout).
+template <int KS2, int ST, int RING>
+constexpr int scan_i8x16_lds_bytes() { return RING * (ST * 2 * KS2 * 64 * 16 + ST * 32 * 4); }
+
+// (the body is a device function over a caller-provided LDS block so that scan_pair_x16_kernel, scan_x16.hpp, can hold it
+//  next to the fp16 scan in ONE launch)
 template <int KS2, int ST, int CB, int NWAVES = 8, bool DBG = false, int RING = 2, int AUX = 0>
-__global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16_kernel(ScanI8Args a) {
+__device__ __forceinline__ void scan_i8x16_body(const ScanI8Args &a, unsigned char *smem) {
     constexpr int NV = 2 * KS2;                           // 16-byte fragments per lane and tile
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * NV * 64;               // 16-byte vectors per stage
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
     static_assert(TPS % ST == 0 && ST >= 2 && CB % 2 == 0 && NWAVES <= 8, "bad geometry");
     static_assert(RING >= 2 && RING <= 8 && (RING == 2 || ST % 2 == 0), "bad ring");
     constexpr bool kDeep = RING > 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * (kStageVec * 16 + ST * 32 * 4)];
+    static_assert(scan_i8x16_lds_bytes<KS2, ST, RING>() == RING * (kStageVec * 16 + ST * 32 * 4), "LDS size");
     const int mode = a.info->i8_mode;
     if (!mode) return;                                    // this batch is served by the fp16 scan
     auto lds_a = [&](int buf) { return reinterpret_cast<int4v *>(smem + buf * (kStageVec * 16)); };
@@ -325,6 +330,12 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16
         a.sb_m2[so + j * 32] = __int_as_float(M2[j]);
         a.sb_span[so + j * 32] = Ms[j];
     }
+}
+
+template <int KS2, int ST, int CB, int NWAVES = 8, bool DBG = false, int RING = 2, int AUX = 0>
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_i8x16_kernel(ScanI8Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[scan_i8x16_lds_bytes<KS2, ST, RING>()];
+    scan_i8x16_body<KS2, ST, CB, NWAVES, DBG, RING, AUX>(a, smem);
 }
 
 }  // namespace vdb

@@ -18,8 +18,11 @@
 
 namespace vdb {
 
-template <int KS2, int NWAVES, int ST, int WPS, int BR = 256, bool DBG = false>
-__global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) {
+template <int KS2, int ST>
+constexpr int scan_x16_lds_bytes() { return 2 * (ST * 2 * KS2 * 64 * 16 + ST * 32 * 4); }
+
+template <int KS2, int NWAVES, int ST, int BR = 256, bool DBG = false>
+__device__ __forceinline__ void scan_x16_body(const ScanArgs &a, unsigned char *smem) {
     constexpr int NV = 2 * KS2, CB = 4;
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * NV * 64;
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
     constexpr int NS = kMerge ? CB / 2 : CB;               // column blocks whose bins a lane stores
     constexpr int UNR = ST <= 4 ? ST : 1;                  // tiles of a stage unrolled together (8-tile stages keep the loop rolled)
     static_assert(TPS % ST == 0 && ST >= 2 && BT % ST == 0 && (BR == 256 || BR == 128 || BR == 64), "bad geometry");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (kStageVec * 16 + ST * 32 * 4)];
+    static_assert(scan_x16_lds_bytes<KS2, ST>() == 2 * (kStageVec * 16 + ST * 32 * 4), "LDS size");
     auto lds_a = [&](int buf) { return reinterpret_cast<half8 *>(smem + buf * (kStageVec * 16)); };
     auto lds_b = [&](int buf) { return reinterpret_cast<float *>(smem + 2 * kStageVec * 16 + buf * (ST * 32 * 4)); };
     if (a.info->i8_mode) return;                            // this batch is served by the int8 scan
@@ -284,6 +287,27 @@ __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) 
             a.sb_span[so + j * CS] = Ms[j];
         }
     }
+}
+
+template <int KS2, int NWAVES, int ST, int WPS, int BR = 256, bool DBG = false>
+__global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[scan_x16_lds_bytes<KS2, ST>()];
+    scan_x16_body<KS2, NWAVES, ST, BR, DBG>(a, smem);
+}
+
+// Both scans of an index that holds the int8 copy, in ONE launch: which of them serves a batch is decided on the device
+// (QueryBatchInfo.i8_mode), so both used to be enqueued and the one not needed returned at once -- a 4.5 us dispatch plus its gap on
+// every search, a tenth of a single-query search.  Here every workgroup reads the flag and runs the body of the scan that serves the
+// batch; the grid is the larger of the two (the body's own chunk test retires the workgroups beyond its grid), the LDS block the
+// larger of the two, registers the larger of the two (254 / 226: both kernels already run 2 waves per SIMD).
+// W128: D in (64, 128] (fp16 KS2 = 4, int8 KS2 = 2), else D <= 64 (2 / 1).  STF: tiles per fp16 stage; STI / CBI / RING / AUX: the int8 shape.
+template <bool W128, int NWAVES, int STF, int STI, int CBI, int RING, int AUX>
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES >= 4 ? 2 : 1)) void scan_pair_x16_kernel(ScanArgs a16, ScanI8Args a8) {
+    constexpr int KF = W128 ? 4 : 2, KI = W128 ? 2 : 1;
+    constexpr int kLds16 = scan_x16_lds_bytes<KF, STF>(), kLds8 = scan_i8x16_lds_bytes<KI, STI, RING>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLds16 > kLds8 ? kLds16 : kLds8];
+    if (a8.info->i8_mode) scan_i8x16_body<KI, STI, CBI, NWAVES, false, RING, AUX>(a8, smem);
+    else scan_x16_body<KF, NWAVES, STF, 256, false>(a16, smem);
 }
 
 }  // namespace vdb

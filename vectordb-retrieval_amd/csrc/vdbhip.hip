@@ -196,6 +196,7 @@ struct vdb_index_s {
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
     int f16_stage_tiles = 0;                 // option "f16_stage_tiles" (tuning, x16 fp16 batch scan): tiles per LDS stage, 0 auto | 4 | 8
+    int scan_pair_off = 0;                   // option "scan_pair" = 0: never the paired launch of the two x16 scans (A/B, diagnosis)
     int scan_prio = 0;                       // option "scan_prio" (tuning, x16 kernels): issue priority of one half of the workgroup's waves
     int flat_shape_opt = 0;                  // option "flat_shape" (alias "i8_shape"; before vdb_add): MFMA shape of the flat scans for D <= 128,
                                              // 0 auto (16) | 16 | 32
@@ -243,6 +244,7 @@ struct vdb_index_s {
     // options
     int force_path = 0, timing = 0, list_cap = 0, scan_variant = 0, select_variant = 0, spc_override = 0, kloop_qgroup = 0;
     int layout_override = 0;                 // option "panel_layout": 1 = keep 32-row tiles for D > 128 (A/B runs)
+    bool small_clear_pending = false;        // search_device_impl left the clearing of ws.small to the first batch (serving-shaped calls)
     bool small_is_clean = false;             // ws.small was cleared for this call and no batch has used it yet
     bool small_preset = false;               // coarse quantizer of an IVF index: the parent has just cleared ws.small (it lives in
                                              // the parent's ivf_zero buffer) -- the next search_device_impl skips its own memset
@@ -1292,6 +1294,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "f16_stage_tiles") {
             if (value != 0 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "f16_stage_tiles must be 0, 4 or 8");
             h->f16_stage_tiles = (int)value;
+        } else if (k == "scan_pair") {         // 1 (default): both x16 scans of an index with an int8 copy in one launch; 0: two launches
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "scan_pair must be 0 or 1");
+            h->scan_pair_off = value == 0;
         } else if (k == "scan_prio") {
             if (value < 0 || value > 2) throw Error(VDB_ERR_INVALID, "scan_prio must be 0, 1 or 2");
             h->scan_prio = (int)value;
