@@ -9,7 +9,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection
     group = os.path.relpath(f, root).split(os.sep)[0].replace("pmc_", "").rsplit("_", 1)[0]
     for r in csv.DictReader(open(f)):
         agg[group][r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-want = ("scan_i8_kernel", "scan_i8x16_kernel", "scan_x16_kernel", "scan_kernel", "ivf_kloop_scan_kernel", "scan16_kloop", "ivf_select", "refine_list", "select_kernel", "dense_")
+want = ("scan_i8_kernel", "scan_pair_x16_kernel", "scan_i8x16_kernel", "scan_x16_kernel", "scan_kernel", "ivf_kloop_scan_kernel", "scan16_kloop", "ivf_select", "refine_list", "select_kernel", "dense_")
 for group, kernels in agg.items():
     print(f"==== {group}")
     for k, cs in kernels.items():

@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, sys
 root = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 WANT = {  # pass group -> (json key, substrings the kernel name must contain; "a|b" = either)
-    "sift1m": ("sift1m_i8", ("scan_i8x16_kernel|scan_i8_kernel",)),
+    "sift1m": ("sift1m_i8", ("scan_pair_x16_kernel|scan_i8x16_kernel|scan_i8_kernel",)),
     "ivf8": ("ivf1024_nprobe8", ("scan_i8_kernel", "true")),
     "ivf128": ("ivf1024_nprobe128", ("scan_i8_kernel", "true")),
     "msmarco": ("msmarco_ivf_nprobe32", ("ivf_kloop_scan_kernel",)),
@@ -41,7 +41,7 @@ for group, (key, must) in WANT.items():
         continue
     kernel, fetch, write, launches = best
     keep = {k: v for k, v in table.get(key, {}).items() if k == "algorithmic_bytes_per_launch"}
-    table[key] = {"kernel": kernel.replace("void vdb::", "").replace("(vdb::ScanI8Args)", "").replace("(vdb::ScanArgs)", "").replace(" ", ""),
+    table[key] = {"kernel": kernel.replace("void vdb::", "").replace("(vdb::ScanI8Args)", "").replace("(vdb::ScanArgs)", "").replace("(vdb::ScanArgs,vdb::ScanI8Args)", "").replace(" ", ""),
                   "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
                   "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "launches_averaged": launches, "correction": CORR,
                   "source": f"profiles/{TAG}_pmc_summary.txt (scripts/final_profiles_{TAG}.sh, separate --pmc passes '{group}_fetch' / '{group}_write')",
