@@ -567,7 +567,8 @@ def roofline_of(st, nq, n, d, workload, ivf_rows_probed=None, traffic_key=None):
         # (an index with an int8 copy runs both scans from ONE launch, scan_pair_x16_kernel: the device picks the body)
         pair = int(st.get("has_i8_copy", 0)) == 1
         kernel = (("scan_pair_x16_kernel -> " if pair else "") +
-                  ("scan_i8x16_body<%d>" % (1 if d <= 64 else 2) if i8 else "scan_x16_%s<%d>" % ("body" if pair else "kernel", 2 if d <= 64 else 4)))
+                  ("scan_i8x16_%s<%d>" % ("body" if pair else "kernel", 1 if d <= 64 else 2) if i8 else
+                   "scan_x16_%s<%d>" % ("body" if pair else "kernel", 2 if d <= 64 else 4)))
     elif d <= 128:
         kernel = "scan_i8_kernel" if i8 else "scan_kernel<%d>" % (4 if d <= 64 else 8)
     else:
