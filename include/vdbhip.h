@@ -253,8 +253,9 @@ int vdb_stats(vdb_handle h, vdb_stats_t *out);
  *                       -- "f16_group" / "i8_group" = 4 -- or for an A/B schedule of "scan_variant")
  *     "scan_pair"       layout "x16", index with an int8 copy: 1 (default) both scans in one launch (the device picks the body), 0 two
  *                       launches (the one not needed returns at once) -- A/B and diagnosis
- *     "f16_stage_tiles" / "scan_prio"   tuning of the x16 kernels (tiles per LDS stage of the fp16 batch scan: 0 auto | 4 | 8; issue
- *                       priority of one half of a workgroup: 0 | 1 | 2 -- measured, no gain)
+ *     "f16_stage_tiles" / "f16_wide" / "scan_prio"   tuning of the x16 kernels (tiles per LDS stage of the fp16 batch scan: 0 auto | 4 | 8;
+ *                       1024-query workgroup tiles of the fp16 scan at D <= 64: 0 auto | 1 never; issue priority of one half of a
+ *                       workgroup: 0 | 1 | 2 -- measured, no gain)
  *     "f16_group"       8 (default) | 4 rows per select group of the fp16 flat scan (D <= 128)
  *     "i8_ring"         0 auto (4) | 2 | 4 | 8 LDS staging stages of the serving-shaped and IVF int8 scans
  *     "i8_nt"           0 (default) / 2: the serving-shaped int8 scan stages its panels with non-temporal loads | 1 off

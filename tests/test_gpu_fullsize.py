@@ -117,7 +117,23 @@ def test_gaussian1m_and_glove_shapes(vdb, oracle):
         Do, Io = oracle.knn(X, Q[sample], 10, metric)
         np.testing.assert_array_equal(I[sample], Io)
         np.testing.assert_array_equal(D[sample], Do)
+        # the other launch forms of the x16 fp16 scan on the full batch: 512-query tiles (D <= 64 takes 1024-query tiles by default),
+        # 4- / 8-tile stages, and the 32x32x16 kernel on its own layout -- all bit-identical
+        assert st["scan_shape"] == 16
+        for opt, v in (("f16_wide", 1), ("f16_stage_tiles", 4), ("f16_stage_tiles", 8)):
+            idx.set_option(opt, v)
+            D2, I2 = idx.search(Q, 10)
+            np.testing.assert_array_equal(I2, I)
+            np.testing.assert_array_equal(D2, D)
         idx.close()
+        old = vdb.FlatIndex(X.shape[1], metric, 0)
+        old.set_option("flat_shape", 32)
+        old.add(X)
+        D3, I3 = old.search(Q, 10)
+        assert old.stats()["scan_shape"] == 32
+        np.testing.assert_array_equal(I3, I)
+        np.testing.assert_array_equal(D3, D)
+        old.close()
 
 
 def test_glove_shape_cosine_through_the_plugin(vdb, oracle):

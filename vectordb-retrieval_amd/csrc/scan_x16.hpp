@@ -23,9 +23,12 @@ constexpr int scan_x16_lds_bytes() { return 2 * (ST * 2 * KS2 * 64 * 16 + ST * 3
 
 // G: rows per candidate group -- 8 (octs), or 4 (quads: the lane's four rows of each block; direct-bin mode, where k is large and the
 // exact refine of the float32 rows outweighs the scan, so the smaller group wins: 10k queries, k = 100 on 50k rows 1.20 -> 0.97 ms)
-template <int KS2, int NWAVES, int ST, int BR = 256, bool DBG = false, int G = 8>
+// CB: 16-query column blocks per wave: 4 (64 queries), or for D <= 64 also 8 (128 queries per wave, 1024-query workgroup tiles as
+// scan_i8x16_kernel: every A fragment read from LDS feeds 8 MFMAs; at D = 128 the B fragments of 128 queries would take 128 VGPRs)
+template <int KS2, int NWAVES, int ST, int BR = 256, bool DBG = false, int G = 8, int CB = 4>
 __device__ __forceinline__ void scan_x16_body(const ScanArgs &a, unsigned char *smem) {
-    constexpr int NV = 2 * KS2, CB = 4;
+    constexpr int NV = 2 * KS2;
+    static_assert(CB == 4 || (CB == 8 && KS2 <= 2), "128 queries per wave: D <= 64");
     constexpr int NT = NWAVES * 64;
     constexpr int kStageVec = ST * NV * 64;
     constexpr int kBiasLoads = (ST * 32 + NT - 1) / NT;
@@ -53,7 +56,7 @@ __device__ __forceinline__ void scan_x16_body(const ScanArgs &a, unsigned char *
     int chunk = x + 8 * ci;
     if (chunk >= a.nchunks) return;
     chunk += a.chunk0;                                      // (a slab launch of an int8-only index)
-    const int64_t q0 = (int64_t)qt * (NWAVES * 64) + wave * 64;
+    const int64_t q0 = (int64_t)qt * (NWAVES * 16 * CB) + wave * (16 * CB);
     const int64_t span0 = chunk_span0(chunk, a.spans_per_chunk, a.chunk_rem);
     int64_t span1 = chunk_span0(chunk + 1, a.spans_per_chunk, a.chunk_rem);
     if (span1 > a.nspans) span1 = a.nspans;
@@ -302,10 +305,10 @@ __device__ __forceinline__ void scan_x16_body(const ScanArgs &a, unsigned char *
     }
 }
 
-template <int KS2, int NWAVES, int ST, int WPS, int BR = 256, bool DBG = false, int G = 8>
+template <int KS2, int NWAVES, int ST, int WPS, int BR = 256, bool DBG = false, int G = 8, int CB = 4>
 __global__ __launch_bounds__(NWAVES * 64, WPS) void scan_x16_kernel(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[scan_x16_lds_bytes<KS2, ST>()];
-    scan_x16_body<KS2, NWAVES, ST, BR, DBG, G>(a, smem);
+    scan_x16_body<KS2, NWAVES, ST, BR, DBG, G, CB>(a, smem);
 }
 
 // Both scans of an index that holds the int8 copy, in ONE launch: which of them serves a batch is decided on the device

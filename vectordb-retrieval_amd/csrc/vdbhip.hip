@@ -195,6 +195,7 @@ struct vdb_index_s {
     int ivf_group = 0;                       // option "ivf_group": rows per candidate group of the D > 128 list scan (0 auto, 1, 2, 4)
     int ivf_nw = 0;                          // option "ivf_nw": waves per IVF work item (0 auto, 2 / 4 / 8)
     int i8_group = 8;                        // rows per select group of the int8 scan (option "i8_group": 4 or 8)
+    int f16_wide = 0;                        // option "f16_wide" (tuning, x16 fp16 batch scan, D <= 64): 0 auto (1024-query tiles when they fit), 1 never
     int f16_stage_tiles = 0;                 // option "f16_stage_tiles" (tuning, x16 fp16 batch scan): tiles per LDS stage, 0 auto | 4 | 8
     int scan_pair_off = 0;                   // option "scan_pair" = 0: never the paired launch of the two x16 scans (A/B, diagnosis)
     int scan_prio = 0;                       // option "scan_prio" (tuning, x16 kernels): issue priority of one half of the workgroup's waves
@@ -1291,6 +1292,9 @@ int vdb_set_option(vdb_handle hh, const char *key, double value) {
         } else if (k == "kloop_qgroup") {
             if (value < 0 || value > 1024) throw Error(VDB_ERR_INVALID, "kloop_qgroup out of range");
             h->kloop_qgroup = (int)value;
+        } else if (k == "f16_wide") {
+            if (value != 0 && value != 1) throw Error(VDB_ERR_INVALID, "f16_wide must be 0 or 1");
+            h->f16_wide = (int)value;
         } else if (k == "f16_stage_tiles") {
             if (value != 0 && value != 4 && value != 8) throw Error(VDB_ERR_INVALID, "f16_stage_tiles must be 0, 4 or 8");
             h->f16_stage_tiles = (int)value;
